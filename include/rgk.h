@@ -1,0 +1,252 @@
+/*
+ * rgk.h -- C ABI of the MI355X path-tracing core (librgk_hip.so).
+ *
+ * This is the drop-in boundary for the per-tile body of the reference's
+ * RenderDriver::RenderRound (reference src/render_driver.cpp:144-190): the
+ * lambda that builds a PathTracer (src/path_tracer.cpp:20-40), calls
+ * Tracer::Render (src/tracer.cpp:6-37) on one RenderTask and merges the
+ * private EXRTexture into the frame accumulator (src/texture.cpp:403-412).
+ *
+ * Plain C, plain pointers and sizes.  No C++ or torch types cross it.
+ * Every entry point returns RGK_OK (0) or a negative rgk_status; nothing
+ * throws across the ABI.  rgk_last_error() gives a thread-local message.
+ *
+ * All arithmetic on the path is float32 except the two plane dot products of
+ * the triangle test (double, reference src/primitives.cpp:85,99-100).
+ */
+#ifndef RGK_H
+#define RGK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rgk_status {
+    RGK_OK = 0,
+    RGK_ERR_INVALID = -1,   /* bad descriptor / argument                       */
+    RGK_ERR_DEVICE = -2,    /* HIP runtime failure (message in rgk_last_error) */
+    RGK_ERR_OOM = -3,       /* host or device allocation failed                */
+    RGK_ERR_NO_DEVICE = -4, /* no HIP device visible                           */
+    RGK_ERR_UNSUPPORTED = -5
+} rgk_status;
+
+/* ---- materials: mirrors Material + BxDF subclasses, src/bxdf/bxdf.hpp:19-159,
+ *      brdf ids accepted by Material::LoadFromJson src/bxdf/bxdf.cpp:63-84 ---- */
+typedef enum rgk_bxdf_kind {
+    RGK_BXDF_DIFFUSE = 0,              /* "diffuse"/"diffusecosine"  bxdf.cpp:192-204 */
+    RGK_BXDF_MIRROR = 1,               /* "mirror"                   bxdf.cpp:265-276 */
+    RGK_BXDF_DIELECTRIC = 2,           /* "dielectric"               bxdf.cpp:332-408 */
+    RGK_BXDF_TRANSPARENT = 3,          /* "transparent"              bxdf.cpp:412-423 */
+    RGK_BXDF_MIX = 4,                  /* "mix"                      bxdf.cpp:235-249 */
+    RGK_BXDF_LTC_BECKMANN = 5,         /* "ltc_beckmann"             bxdf.hpp:107-122 */
+    RGK_BXDF_LTC_GGX = 6,              /* "ltc_ggx"                                   */
+    RGK_BXDF_LTC_BECKMANN_DIFFUSE = 7, /* "ltc_beckmann_diffuse"     bxdf.hpp:125-159 */
+    RGK_BXDF_LTC_GGX_DIFFUSE = 8       /* "ltc_ggx_diffuse"                           */
+} rgk_bxdf_kind;
+
+#define RGK_MAT_NO_RUSSIAN 1u /* Material::no_russian, bxdf.hpp:31 */
+
+typedef struct rgk_material {
+    uint32_t kind;       /* rgk_bxdf_kind */
+    uint32_t flags;      /* RGK_MAT_* */
+    float emission[3];   /* Material::emission */
+    float roughness;     /* BxDFLTCBase::roughness */
+    float ior;           /* BxDFDielectric::ior */
+    float amount;        /* BxDFMix::amt1 */
+    int32_t tex_diffuse; /* texture id or -1 (EmptyTexture: black, Empty()==true) */
+    int32_t tex_color;   /* specular / mirror / dielectric colour texture, or -1 */
+    int32_t tex_bump;    /* Material::bumpmap, or -1 */
+    int32_t mix_m1;      /* BxDFMix::m1 material index, or -1 */
+    int32_t mix_m2;      /* BxDFMix::m2 */
+} rgk_material;
+
+/* ---- textures: ReadableTexture family, src/texture.hpp:10-80 ---- */
+typedef enum rgk_texture_kind {
+    RGK_TEX_SOLID = 0, /* SolidTexture: constant colour, slopes 0 */
+    RGK_TEX_RGB32F = 1 /* FileTexture: width*height Color{r,g,b} float triples, row-major,
+                          already gamma-decoded / flipped as the reference loader does */
+} rgk_texture_kind;
+
+typedef struct rgk_texture {
+    uint32_t kind;
+    uint32_t width, height;
+    float color[3];      /* RGK_TEX_SOLID */
+    const float *texels; /* RGK_TEX_RGB32F: 3*width*height floats */
+} rgk_texture;
+
+/* ---- point / sphere lights: Light{FULL_SPHERE}, src/primitives.hpp:26-43,
+ *      filled by ConfigJSON::InstallLights src/config.cpp:372-387 ---- */
+typedef struct rgk_pointlight {
+    float pos[3];
+    float color[3];
+    float intensity;
+    float size;
+} rgk_pointlight;
+
+typedef enum rgk_sky_mode { RGK_SKY_COLOR = 0, RGK_SKY_ENVMAP = 1 } rgk_sky_mode;
+
+/* ---- the immutable Scene as it crosses the seam (src/scene.hpp:76-172) ---- */
+typedef struct rgk_scene_desc {
+    uint32_t n_vertices;
+    const float *vertices;  /* 3*n  Scene::vertices  */
+    const float *normals;   /* 3*n  Scene::normals   */
+    const float *tangents;  /* 3*n  Scene::tangents  */
+    const float *texcoords; /* 2*n  Scene::texcoords */
+
+    uint32_t n_triangles;
+    const uint32_t *tri_indices;  /* 3*n  Triangle::va,vb,vc */
+    const uint32_t *tri_material; /* n    Triangle::mat as an index */
+
+    uint32_t n_materials;
+    const rgk_material *materials;
+    uint32_t n_textures;
+    const rgk_texture *textures;
+
+    uint32_t n_pointlights;
+    const rgk_pointlight *pointlights;
+
+    /* Scene::areal_lights (src/scene.hpp:91-103): one group per emissive
+     * primitive / mesh, listing its triangle ids in insertion order.       */
+    uint32_t n_areal_lights;
+    const uint32_t *areal_offsets; /* n_areal_lights+1 */
+    const uint32_t *areal_tris;
+
+    /* sky, Scene::SetSkyboxColor / SetSkyboxEnvmap src/scene.hpp:122-133 */
+    uint32_t sky_mode;
+    float sky_color[3];
+    float sky_intensity;
+    float sky_rotate;
+    int32_t sky_texture;
+
+    /* LTC fits (src/LTC/ltc_ggx.cpp, ltc_beckmann.cpp): 64*64 entries of
+     * {m0,m2,m4,m6,amplitude} as float32 (the only non-constant entries of
+     * tabM; m8==1, the rest 0).  Either may be NULL if no material uses it. */
+    const float *ltc_ggx;
+    const float *ltc_beckmann;
+} rgk_scene_desc;
+
+/* ---- Camera constructor arguments, src/camera.cpp:7 ---- */
+typedef struct rgk_camera {
+    float pos[3], lookat[3], up[3];
+    float yview, xview;
+    int32_t xsize, ysize;
+    float focus_plane, lens_size;
+} rgk_camera;
+
+typedef enum rgk_sampler_kind {
+    RGK_SAMPLER_HALTON = 0,    /* counter-based Faure-Halton + Cranley-Patterson */
+    RGK_SAMPLER_STRATIFIED = 1 /* oracle only: reference StratifiedSampler, src/sampler.cpp:85-116 */
+} rgk_sampler_kind;
+
+#define RGK_FLAG_COUNT_TRAVERSAL 1u /* fill node_visits / tri_tests (slower kernels) */
+#define RGK_FLAG_TIME_KERNELS 2u    /* bracket every kernel class with HIP events     */
+
+/* ---- PathTracer constructor arguments, src/path_tracer.cpp:20-40 ---- */
+typedef struct rgk_params {
+    uint32_t xres, yres;
+    uint32_t multisample;
+    uint32_t depth;
+    float clamp;
+    float russian;
+    float bumpmap_scale;
+    uint32_t force_fresnell; /* stored, unused -- as in the reference */
+    uint32_t reverse;
+    uint32_t sampler; /* rgk_sampler_kind */
+    uint32_t flags;   /* RGK_FLAG_* */
+} rgk_params;
+
+/* ---- RenderTask (src/tracer.hpp:14-24) + its PathTracer seed
+ *      (seedstart + c, src/render_driver.cpp:160,173) ---- */
+typedef struct rgk_tile {
+    uint32_t x0, x1, y0, y1; /* xrange_start, xrange_end, yrange_start, yrange_end */
+    uint32_t seed;
+} rgk_tile;
+
+typedef struct rgk_counters {
+    uint64_t paths;        /* pixels * multisample processed                      */
+    uint64_t path_rays;    /* reference semantics: raycount++ path_tracer.cpp:126 */
+    uint64_t shadow_rays;  /* Visibility() calls                                  */
+    uint64_t node_visits;  /* closest-hit traversal, RGK_FLAG_COUNT_TRAVERSAL     */
+    uint64_t tri_tests;
+    uint64_t shadow_node_visits;
+    uint64_t shadow_tri_tests;
+    double ms_trace;       /* RGK_FLAG_TIME_KERNELS: summed HIP-event time, ms    */
+    double ms_shadow;
+    double ms_shade;
+    double ms_other;
+    uint32_t n_trace_launches;
+    uint32_t n_shadow_launches;
+    uint32_t n_shade_launches;
+    uint32_t reserved;
+} rgk_counters;
+
+typedef struct rgk_scene_info {
+    float epsilon;        /* Scene::epsilon, src/scene.cpp:390   */
+    float bbox_min[3];    /* xBB/yBB/zBB .first,  scene.cpp:393  */
+    float bbox_max[3];
+    float total_areal_power, total_point_power; /* scene.cpp:323-344 */
+    uint32_t n_nodes;     /* accelerator nodes                    */
+    uint32_t node_bytes;  /* s_node of SURVEY 8(d)                */
+    uint32_t tri_bytes;   /* s_tri                                */
+    uint32_t max_depth;
+    uint32_t n_leaf_refs;
+} rgk_scene_info;
+
+typedef struct rgk_hit {
+    float t;
+    int32_t tri; /* triangle index or -1 */
+    float a, b, c; /* Intersection::a,b,c  (c'=1-alpha-beta, alpha, beta) scene_intersect.cpp:280-283 */
+} rgk_hit;
+
+typedef struct rgk_scene rgk_scene;
+
+const char *rgk_last_error(void);
+int rgk_device_count(void);
+
+/* Scene::Commit() outputs (src/scene.cpp:294-400) + accelerator build + upload. */
+int rgk_scene_create(const rgk_scene_desc *desc, int device, rgk_scene **out);
+void rgk_scene_destroy(rgk_scene *scene);
+int rgk_scene_get_info(const rgk_scene *scene, rgk_scene_info *out);
+
+/* GenerateTaskList, src/render_driver.cpp:30-46.  Tiles of tile_size, sorted by
+ * distance of the tile midpoint to (mid_x, mid_y); ties broken by (y0, x0)
+ * (the reference's std::sort leaves ties unspecified).  `seed` of
+ * tile i is seedstart + seedcount_base + i.  Call with tiles==NULL for the count. */
+int rgk_generate_task_list(uint32_t tile_size, uint32_t xres, uint32_t yres, float mid_x,
+                           float mid_y, uint32_t seedstart, uint32_t seedcount_base,
+                           rgk_tile *tiles, uint32_t *n_tiles);
+
+/* The per-task body of RenderRound for a list of tiles (render_driver.cpp:158-184):
+ * accum_rgb[3*(y*xres+x)..] += sum over samples, accum_count[y*xres+x] += multisample.
+ * Host buffers; blocking. */
+int rgk_render_round(rgk_scene *scene, const rgk_camera *camera, const rgk_params *params,
+                     const rgk_tile *tiles, uint32_t n_tiles, float *accum_rgb,
+                     uint32_t *accum_count, rgk_counters *counters);
+
+/* Same, adding into DEVICE buffers on the scene's GPU (the per-GPU private
+ * accumulator that RCCL then reduces).  Blocking unless the stream is the caller's. */
+int rgk_render_round_device(rgk_scene *scene, const rgk_camera *camera,
+                            const rgk_params *params, const rgk_tile *tiles, uint32_t n_tiles,
+                            float *d_accum_rgb, uint32_t *d_accum_count,
+                            rgk_counters *counters);
+
+/* Scene::FindIntersectKdOtherThan (src/scene_intersect.cpp:211-327) for n rays.
+ * rays: 8 floats each {ox,oy,oz, dx,dy,dz, near, far}; ignore: triangle id or -1. */
+int rgk_trace_closest(rgk_scene *scene, uint32_t n, const float *rays, const int32_t *ignore,
+                      rgk_hit *hits, rgk_counters *counters);
+
+/* Scene::Visibility (src/scene.cpp:670-673) for n point pairs (3 floats each). */
+int rgk_trace_visibility(rgk_scene *scene, uint32_t n, const float *a, const float *b,
+                         uint8_t *visible, rgk_counters *counters);
+
+/* Sampler::Get1D / Get2D of the build's Halton sampler evaluated on the device:
+ * out[2*i..] = sample of (seed[i], index[i], dim[i]); is2d selects Get2D. */
+int rgk_sampler_eval(uint32_t n, const uint32_t *seed, const uint32_t *index,
+                     const uint32_t *dim, int is2d, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RGK_H */

@@ -1,0 +1,363 @@
+"""JSON config front-end: the host-side mirror of the reference's ConfigJSON.
+
+Follows reference src/config.cpp:260-326 (CreateFromFile: scalar fields and their
+defaults), :328-370 (GetCamera), :372-387 (InstallLights), :389-413 (InstallSky),
+:415-543 (InstallScene), :545-558 (InstallMaterials) and the typed getters of
+src/jsonutils.cpp:21-120 (incl. the `key255` variants that divide by 255).
+JSON is parsed with `//` and `/* */` comments allowed (jsoncpp Reader behaviour).
+"""
+import json
+import math
+import os
+
+import numpy as np
+
+from . import capi
+from .scene import SceneBuilder
+
+f32 = np.float32
+
+
+class ConfigFileException(RuntimeError):
+    """src/config.hpp:16-18"""
+
+
+def strip_json_comments(text):
+    out = []
+    i, n = 0, len(text)
+    in_str = False
+    while i < n:
+        c = text[i]
+        if in_str:
+            out.append(c)
+            if c == "\\" and i + 1 < n:
+                out.append(text[i + 1])
+                i += 1
+            elif c == '"':
+                in_str = False
+        elif c == '"':
+            in_str = True
+            out.append(c)
+        elif c == "/" and i + 1 < n and text[i + 1] == "/":
+            while i < n and text[i] != "\n":
+                i += 1
+            continue
+        elif c == "/" and i + 1 < n and text[i + 1] == "*":
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            continue
+        else:
+            out.append(c)
+        i += 1
+    return "".join(out)
+
+
+def _vec3(v, what):
+    if isinstance(v, (list, tuple)):
+        if len(v) != 3 or not all(isinstance(x, (int, float)) and not isinstance(x, bool) for x in v):
+            raise ConfigFileException(f'value "{what}" must be an array of 3 numbers or a single number.')
+        return np.array(v, dtype=f32)
+    if isinstance(v, (int, float)) and not isinstance(v, bool):
+        return np.array([v, v, v], dtype=f32)
+    raise ConfigFileException(f'value "{what}" must be an array of 3 numbers or a single number.')
+
+
+class Node:
+    """A JSON object with the reference's typed getters and used-key tracking."""
+
+    def __init__(self, d, name):
+        self.d, self.name, self.used = d, name, set()
+
+    def has(self, k):
+        return k in self.d
+
+    def _num(self, k, kind):
+        v = self.d[k]
+        if isinstance(v, bool) or not isinstance(v, (int, float)):
+            raise ConfigFileException(f'{kind} value "{k}" in {self.name} must be a number.')
+        self.used.add(k)
+        return v
+
+    def req_str(self, k):
+        if k not in self.d:
+            raise ConfigFileException(f'Required value "{k}" is missing from {self.name}.')
+        if not isinstance(self.d[k], str):
+            raise ConfigFileException(f'Required value "{k}" in {self.name} must be a string.')
+        self.used.add(k)
+        return self.d[k]
+
+    def req_int(self, k):
+        if k not in self.d:
+            raise ConfigFileException(f'Required value "{k}" is missing from {self.name}.')
+        return int(self._num(k, "Required"))
+
+    def req_float(self, k):
+        if k not in self.d:
+            raise ConfigFileException(f'Required value "{k}" is missing from {self.name}.')
+        return f32(self._num(k, "Required"))
+
+    def req_vec3(self, k):
+        if k not in self.d:
+            raise ConfigFileException(f'Required value "{k}" is missing from {self.name}.')
+        self.used.add(k)
+        return _vec3(self.d[k], k)
+
+    def req_vec3_255(self, k):
+        if k in self.d:
+            return self.req_vec3(k)
+        if k + "255" in self.d:
+            self.used.add(k + "255")
+            return _vec3(self.d[k + "255"], k + "255") / f32(255.0)
+        raise ConfigFileException(f'Required value "{k}" is missing from {self.name}.')
+
+    def opt_str(self, k, d):
+        return self.req_str(k) if k in self.d else d
+
+    def opt_int(self, k, d):
+        return self.req_int(k) if k in self.d else d
+
+    def opt_float(self, k, d):
+        return self.req_float(k) if k in self.d else f32(d)
+
+    def opt_bool(self, k, d):
+        if k not in self.d:
+            return d
+        if not isinstance(self.d[k], bool):
+            raise ConfigFileException(f'Optional value "{k}" in {self.name} must be a bool.')
+        self.used.add(k)
+        return self.d[k]
+
+    def opt_vec3(self, k, d):
+        return self.req_vec3(k) if k in self.d else np.array(d, dtype=f32)
+
+    def opt_vec3_255(self, k, d):
+        if k in self.d or (k + "255") in self.d:
+            return self.req_vec3_255(k)
+        return np.array(d, dtype=f32)
+
+    def unused(self):
+        return [k for k in self.d if k not in self.used]
+
+
+def fov2xview(fov):
+    """src/config.cpp:328-330"""
+    return f32(2.0) * f32(math.tan(float(f32(fov) * f32(0.0174533) / f32(2.0))))
+
+
+class Config:
+    """Scalar fields of reference `Config` (src/config.hpp:27-44) + the parsed root."""
+
+    def __init__(self, path, overrides=None):
+        self.config_file_path = path
+        try:
+            text = open(path).read()
+        except OSError:
+            raise ConfigFileException("Failed to open file: " + path)
+        try:
+            root = json.loads(strip_json_comments(text))
+        except json.JSONDecodeError as e:
+            raise ConfigFileException("Failed to parse JSON contents: " + str(e))
+        if overrides:
+            root.update(overrides)  # BASELINE configs are overrides of the shipped files
+        self.root = Node(root, "the config file")
+        r = self.root
+        self.output_file = r.req_str("output-file")
+        self.xres = r.req_int("output-width")
+        self.yres = r.req_int("output-height")
+        if r.has("rounds") and r.has("render-time"):
+            raise ConfigFileException('The config file may not contain both "rounds" and "render-time" keys simultaneously.')
+        self.render_minutes = None
+        self.render_rounds = 1
+        if r.has("rounds"):
+            self.render_rounds = r.req_int("rounds")
+        elif r.has("render-time"):
+            self.render_minutes = r.req_int("render-time")
+        self.recursion_level = r.opt_int("recursion-max", 40)
+        self.multisample = r.opt_int("multisample", 1)
+        self.clamp = r.opt_float("clamp", 10000000.0)
+        self.bumpmap_scale = r.opt_float("bumpscale", 1.0)
+        self.russian = r.opt_float("russian", 0.74)
+        self.reverse = r.opt_int("reverse", 0)
+        self.force_fresnell = r.opt_bool("force-fresnell", False)
+        self.output_scale = -1.0
+        if r.has("output-scale"):
+            v = r.d["output-scale"]
+            r.used.add("output-scale")
+            if isinstance(v, str):
+                if v != "auto":
+                    raise ConfigFileException('The value of "output-scale" must either be a number, or "auto".')
+            elif isinstance(v, (int, float)) and not isinstance(v, bool):
+                self.output_scale = float(v)
+            else:
+                raise ConfigFileException('The value of "output-scale" must either be a number, or "auto".')
+        self.thinglass = []
+        if r.has("thinglass"):
+            r.used.add("thinglass")
+            t = r.d["thinglass"]
+            if not isinstance(t, list) or not all(isinstance(x, str) for x in t):
+                raise ConfigFileException('Value "thinglass" must be an array of strings')
+            self.thinglass = list(t)
+
+    # ---- src/config.cpp:332-370
+    def get_camera(self, rotation=0.0):
+        r = self.root
+        if not r.has("camera"):
+            raise ConfigFileException('Value "camera" is missing.')
+        r.used.add("camera")
+        if not isinstance(r.d["camera"], dict):
+            raise ConfigFileException('Value "camera" is not a dictionary.')
+        cam = Node(r.d["camera"], "camera configuration")
+        pos = cam.req_vec3("position")
+        lookat = cam.req_vec3("lookat")
+        up = cam.opt_vec3("upvector", (0.0, 1.0, 0.0))
+        if cam.has("focal"):
+            yview = cam.req_float("focal")
+            xview = f32(yview * f32(self.xres)) / f32(self.yres)
+        elif cam.has("fov"):
+            xview = fov2xview(cam.req_float("fov"))
+            yview = f32(xview * f32(self.yres)) / f32(self.xres)
+        else:
+            raise ConfigFileException('Camera must either have a "fov" or "focal" key defined')
+        focus_plane = cam.opt_float("focus-plane", 1.0)
+        lens_size = cam.opt_float("lens-size", 0.0)
+        if rotation != 0.0:
+            from .scene import glm_rotate
+            p = lookat - pos
+            R = glm_rotate(f32(rotation) * f32(2.0) * f32(math.pi), up)[:3, :3]
+            p = (R @ p).astype(f32)
+            pos = lookat - p
+        c = capi.Camera()
+        c.pos[:] = [float(x) for x in pos]
+        c.lookat[:] = [float(x) for x in lookat]
+        c.up[:] = [float(x) for x in up]
+        c.yview, c.xview = float(yview), float(xview)
+        c.xsize, c.ysize = self.xres, self.yres
+        c.focus_plane, c.lens_size = float(focus_plane), float(lens_size)
+        return c
+
+    def get_params(self, sampler=capi.SAMPLER_HALTON, flags=0):
+        """The PathTracer constructor arguments RenderRound passes (render_driver.cpp:164-173)."""
+        p = capi.Params()
+        p.xres, p.yres = self.xres, self.yres
+        p.multisample = self.multisample
+        p.depth = self.recursion_level
+        p.clamp = float(self.clamp)
+        p.russian = float(self.russian)
+        p.bumpmap_scale = float(self.bumpmap_scale)
+        p.force_fresnell = int(self.force_fresnell)
+        p.reverse = self.reverse
+        p.sampler = sampler
+        p.flags = flags
+        return p
+
+    # ---- main.cpp:208-217 order: materials, scene, lights, sky, (thinglass), Commit
+    def build_scene(self, asset_dir=None, mesh_provider=None):
+        sb = SceneBuilder()
+        self.install_materials(sb)
+        self.install_scene(sb, asset_dir, mesh_provider)
+        self.install_lights(sb)
+        self.install_sky(sb)
+        return sb
+
+    def install_materials(self, sb):
+        r = self.root
+        if not r.has("materials"):
+            return
+        r.used.add("materials")
+        mats = r.d["materials"]
+        if not isinstance(mats, list):
+            raise ConfigFileException('The value of "materials" key must be an array of material data')
+        configdir = os.path.dirname(os.path.abspath(self.config_file_path))
+        for i, m in enumerate(mats):
+            sb.load_material_from_json(Node(m, f"material {i} configuration"), configdir, override=True)
+
+    def install_lights(self, sb):
+        r = self.root
+        if not r.has("lights"):
+            return
+        r.used.add("lights")
+        if not isinstance(r.d["lights"], list):
+            raise ConfigFileException('Value "lights" must be an array.')
+        for i, l in enumerate(r.d["lights"]):
+            n = Node(l, f"light {i} configuration")
+            sb.add_point_light(n.req_vec3("position"), n.opt_vec3_255("color", (1.0, 1.0, 1.0)),
+                               n.req_float("intensity"), n.opt_float("size", 0.0))
+
+    def install_sky(self, sb):
+        r = self.root
+        if not r.has("sky"):
+            sb.set_skybox_color((0.0, 0.0, 0.0), 1.0)
+            return
+        r.used.add("sky")
+        if not isinstance(r.d["sky"], dict):
+            raise ConfigFileException('Value "sky" must be a dictionary.')
+        sky = Node(r.d["sky"], "sky configuration")
+        if sky.has("envmap"):
+            configdir = os.path.dirname(os.path.abspath(self.config_file_path))
+            path = sky.req_str("envmap")
+            sb.set_skybox_envmap(os.path.join(configdir, path), sky.opt_float("intensity", 1.0),
+                                 sky.opt_float("rotate", 0.0))
+        elif sky.has("color") or sky.has("color255"):
+            sb.set_skybox_color(sky.req_vec3_255("color"), sky.opt_float("intensity", 1.0))
+        else:
+            raise ConfigFileException('Sky configuration must either contain an "envmap" key or a "color" key')
+
+    def install_scene(self, sb, asset_dir=None, mesh_provider=None):
+        r = self.root
+        configdir = os.path.dirname(os.path.abspath(self.config_file_path))
+        if r.has("model-file") and r.has("scene"):
+            raise ConfigFileException('The input file may not contain both "model-file" key and "scene" key, maximum one of these is allowed.')
+        if r.has("model-file"):
+            rel = r.req_str("model-file")
+            brdf = r.opt_str("brdf", "ltc_ggx")  # read, then ignored by LoadAiSceneMaterials
+            modelfile = _resolve(configdir, rel, asset_dir)
+            if modelfile is None:
+                if mesh_provider is None:
+                    raise ConfigFileException(f'Unable to open model file "{os.path.join(configdir, rel)}"')
+                mesh_provider(sb, rel)  # labelled proxy geometry
+            else:
+                sb.load_obj(modelfile, np.eye(4, dtype=f32), import_materials=True, override_materials=False)
+            del brdf
+        elif r.has("scene"):
+            r.used.add("scene")
+            if not isinstance(r.d["scene"], list):
+                raise ConfigFileException('The value of "scene" key must be an array of objects')
+            for i, o in enumerate(r.d["scene"]):
+                obj = Node(o, f"scene object {i} configuration")
+                if obj.has("file") and obj.has("primitive"):
+                    raise ConfigFileException(f'Both "file" and "primitive" keys found in {obj.name}, only one can be present at a time.')
+                if obj.has("file"):
+                    rel = obj.req_str("file")
+                    import_materials = obj.opt_bool("import-materials", False)
+                    override_materials = obj.opt_bool("override-materials", False)
+                    forced = obj.opt_str("material", "")
+                    smooth = obj.opt_bool("smooth-normals", False)
+                    obj.opt_str("brdf", r.opt_str("brdf", "ltc_ggx"))
+                    T = sb.object_transform(np.eye(4, dtype=f32), obj)
+                    modelfile = _resolve(configdir, rel, asset_dir)
+                    if modelfile is None:
+                        if mesh_provider is None:
+                            raise ConfigFileException(f'Unable to find model file "{os.path.join(configdir, rel)}"')
+                        mesh_provider(sb, rel, T, forced)
+                    else:
+                        sb.load_obj(modelfile, T, import_materials=import_materials,
+                                    override_materials=override_materials, force_mat=forced,
+                                    smooth_normals=smooth)
+                elif obj.has("primitive"):
+                    sb.add_primitive_from_json(obj)
+                else:
+                    raise ConfigFileException(f'Missing mesh data in {obj.name}, it must either contain a "file" key, or "primitive" key.')
+        else:
+            raise ConfigFileException('The input file contains neither "scene" nor "model-file" key.')
+
+    def perform_post_check(self):
+        """src/config.cpp:560-570: keys present but never read."""
+        return self.root.unused()
+
+
+def _resolve(configdir, rel, asset_dir):
+    for base in ([asset_dir] if asset_dir else []) + [configdir]:
+        p = os.path.join(base, rel)
+        if os.path.exists(p):
+            return p
+    return None
