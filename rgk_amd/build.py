@@ -1,0 +1,35 @@
+"""Compile the HIP product library in-tree: rgk_amd/csrc/librgk_hip.so (gfx950)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "librgk_hip.so")
+SOURCES = ["rgk_kernels.hip", "rgk_host.cpp"]
+HEADERS = ["rgk_kernels.h", "rgk_device.h", "device_types.h", os.path.join("..", "..", "include", "rgk.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+         # CPU/GPU agreement: no FMA contraction on either side (DESIGN.md "Numerics")
+         "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function", "-x", "hip"]
+
+
+def up_to_date():
+    if not os.path.exists(LIB):
+        return False
+    t = os.path.getmtime(LIB)
+    return all(os.path.getmtime(os.path.join(CSRC, f)) <= t for f in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=True):
+    if up_to_date() and not force:
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -361,3 +361,30 @@ def _resolve(configdir, rel, asset_dir):
         if os.path.exists(p):
             return p
     return None
+
+
+def make_camera(pos, lookat, up=(0.0, 1.0, 0.0), fov=None, focal=None, xres=1, yres=1, focus_plane=1.0, lens_size=0.0):
+    """A Camera as ConfigJSON::GetCamera builds it (src/config.cpp:332-370) from explicit values."""
+    if focal is not None:
+        yview = f32(focal)
+        xview = f32(yview * f32(xres)) / f32(yres)
+    else:
+        xview = fov2xview(f32(fov))
+        yview = f32(xview * f32(yres)) / f32(xres)
+    c = capi.Camera()
+    c.pos[:] = [float(f32(x)) for x in pos]
+    c.lookat[:] = [float(f32(x)) for x in lookat]
+    c.up[:] = [float(f32(x)) for x in up]
+    c.yview, c.xview = float(yview), float(xview)
+    c.xsize, c.ysize = xres, yres
+    c.focus_plane, c.lens_size = float(focus_plane), float(lens_size)
+    return c
+
+
+def make_params(xres, yres, multisample, depth, clamp=1e7, russian=0.74, bumpscale=1.0, reverse=0,
+                sampler=capi.SAMPLER_HALTON, flags=0):
+    p = capi.Params()
+    p.xres, p.yres, p.multisample, p.depth = xres, yres, multisample, depth
+    p.clamp, p.russian, p.bumpmap_scale = float(f32(clamp)), float(f32(russian)), float(f32(bumpscale))
+    p.force_fresnell, p.reverse, p.sampler, p.flags = 0, reverse, sampler, flags
+    return p

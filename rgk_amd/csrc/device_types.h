@@ -1,0 +1,124 @@
+// Records shared by the host (scene commit / BVH build / upload) and the HIP kernels.
+// Everything here is laid out for 16-byte loads: one lane fetches a whole record with
+// 1-4 dwordx4 instructions.  Sizes are reported through rgk_scene_info (s_node, s_tri
+// of SURVEY 8(d)).
+#pragma once
+#include <stdint.h>
+#include "../../include/rgk.h"
+
+#define RGK_NODE_BYTES 64 // BvhNode
+#define RGK_TRI_BYTES 48  // TriIsect
+
+// BVH2 node, 64 B = 4 x float4.  Children < 0 are leaves: ~child = (first << 4) | (count - 1),
+// `first` indexing TriIsect records stored in leaf order.
+struct BvhNode {
+    float lmin[3], lmax[3]; // left child box
+    float rmin[3], rmax[3]; // right child box
+    int32_t left, right;
+    int32_t pad[2];
+};
+
+// Everything Triangle::TestIntersection (reference src/primitives.cpp:75-166) reads for
+// one triangle, with the vertex differences it recomputes per call hoisted to commit time
+// (same float subtractions on the same operands, so the values are bit-identical).
+struct TriIsect {
+    float n[3], d;       // Triangle::p  (plane, CalculatePlane primitives.cpp:24-36)
+    float v0a, v0b;      // vert0[i1], vert0[i2]
+    float q1x, q1y;      // vert1[i] - vert0[i]
+    float q2x, q2y;      // vert2[i] - vert0[i]
+    uint32_t axes;       // i1 | (i2 << 2)
+    uint32_t tri;        // original triangle index
+};
+
+// Per-vertex shading attributes: {normal.xyz, u}, {tangent.xyz, v}
+struct VtxAttr {
+    float nx, ny, nz, u;
+    float tx, ty, tz, v;
+};
+
+struct TriShade {
+    uint32_t va, vb, vc, mat;
+};
+
+struct DevMaterial { // 64 B
+    uint32_t kind, flags;
+    float emission[3];
+    float roughness, ior, amount;
+    int32_t tex_diffuse, tex_color, tex_bump;
+    int32_t mix_m1, mix_m2;
+    int32_t pad[3];
+};
+
+struct DevTexture { // 32 B
+    uint32_t kind, width, height;
+    float color[3];
+    uint32_t offset; // float offset of texel (0,0) in the texel pool
+    uint32_t pad;
+};
+
+struct DevPointLight {
+    float pos[3];
+    float intensity;
+    float color[3];
+    float size;
+};
+
+struct DevArealLight {
+    float power;      // areal_lights[i].first  (scene.cpp:338-340)
+    float total_area; // ArealLight::total_area
+    float emission[3];
+    uint32_t first, count; // into areal_tris (sorted by area, descending)
+    uint32_t pad;
+};
+
+struct DevArealTri {
+    float area;
+    uint32_t tri;
+    float a[3], b[3], c[3]; // vertices A, B, C of the triangle (GetRandomPoint primitives.cpp:61-73)
+    float normal_a[3];      // GetNormalA()
+};
+
+struct DevHaltonDim { // one Halton dimension of the Faure-permuted sampler
+    uint32_t base;
+    uint32_t digits;    // total digits D the reference's table walk covers
+    uint32_t perm_off;  // into the u16 permutation pool
+    float scale;        // float(0x1.fffffcp-1 / base^D)
+    uint32_t magic;     // division by `base`: q = (mulhi(n, magic) + ((n - mulhi) >> 1)) >> shift
+    uint32_t shift;
+    uint32_t pad[2];
+};
+
+struct DevCamera {
+    float origin[3], direction[3], up[3], left[3];
+    float viewscreen[3], viewscreen_x[3], viewscreen_y[3];
+    float lens_size;
+    int32_t xsize, ysize;
+};
+
+struct DevScene {
+    const BvhNode* nodes;
+    const TriIsect* tris;
+    const TriShade* tri_shade;
+    const VtxAttr* vtx;
+    const DevMaterial* materials;
+    const DevTexture* textures;
+    const float* texels;
+    const DevPointLight* pointlights;
+    const DevArealLight* areal;
+    const DevArealTri* areal_tris;
+    const float* ltc_ggx;      // 4096 x {m0,m2,m4,m6,amp}
+    const float* ltc_beckmann;
+    const DevHaltonDim* hdims;
+    const uint16_t* hperm;
+    uint32_t n_pointlights, n_areal;
+    float total_point_power, total_areal_power;
+    float epsilon;
+    float bb_min[3], bb_max[3];
+    uint32_t has_texcoords;
+    uint32_t sky_mode;
+    float sky_color[3];
+    float sky_intensity, sky_rotate;
+    int32_t sky_texture;
+    int32_t root_is_leaf; // scenes with a single leaf
+    int32_t root_leaf;
+};

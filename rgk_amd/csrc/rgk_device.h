@@ -1,0 +1,512 @@
+// Device-side math for the gfx950 path-tracing kernels.
+//
+// Each function states the reference function whose RESULT it reproduces.  The code is
+// written for the GPU (registers, float4 records, no virtual dispatch), not transcribed:
+// but every float operation that feeds a result is kept in the reference's evaluation
+// order and the library is built with -ffp-contract=off, so that GPU and CPU agree to
+// the last bit everywhere except inside libm (sinf/cosf/acosf/...), see DESIGN.md.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "device_types.h"
+
+#define RGK_PI_F 3.14159265358979323846264338327950288f
+
+struct f3 {
+    float x, y, z;
+};
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ f3 operator*(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ float dot3(f3 a, f3 b) {
+    float tx = a.x * b.x, ty = a.y * b.y, tz = a.z * b.z;
+    return tx + ty + tz;
+}
+__device__ __forceinline__ f3 cross3(f3 x, f3 y) {
+    return mk3(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y);
+}
+__device__ __forceinline__ float len3(f3 v) { return sqrtf(dot3(v, v)); }
+__device__ __forceinline__ f3 norm3(f3 v) { return v * (1.0f / sqrtf(dot3(v, v))); }
+__device__ __forceinline__ float comp(f3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
+__device__ __forceinline__ float max3c(f3 v) { return fmaxf(fmaxf(v.x, v.y), v.z); }
+__device__ __forceinline__ float glm_angle(f3 a, f3 b) { return acosf(fminf(fmaxf(dot3(a, b), -1.0f), 1.0f)); }
+
+struct quatf {
+    float w, x, y, z;
+};
+// q * v, glm semantics
+__device__ __forceinline__ f3 qrot(quatf q, f3 v) {
+    f3 qv = mk3(q.x, q.y, q.z);
+    f3 uv = cross3(qv, v);
+    f3 uuv = cross3(qv, uv);
+    return v + ((uv * q.w) + uuv) * 2.0f;
+}
+__device__ __forceinline__ quatf qinverse(quatf q) {
+    float d = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+    quatf r; r.w = q.w / d; r.x = -q.x / d; r.y = -q.y / d; r.z = -q.z / d;
+    return r;
+}
+__device__ __forceinline__ quatf angle_axis(float a, f3 axis) {
+    float s = sinf(a * 0.5f);
+    quatf r; r.w = cosf(a * 0.5f); r.x = axis.x * s; r.y = axis.y * s; r.z = axis.z * s;
+    return r;
+}
+// RotationBetweenVectors, reference src/glm.cpp:3-33
+__device__ inline quatf rotation_between(f3 start, f3 dest) {
+    start = norm3(start);
+    dest = norm3(dest);
+    float cosTheta = dot3(start, dest);
+    if (cosTheta < -1 + 0.001f) {
+        f3 axis = cross3(mk3(0.0f, 1.0f, 0.0f), start);
+        if ((double)len3(axis) < 0.01) axis = cross3(mk3(1.0f, 0.0f, 0.0f), start);
+        axis = norm3(axis);
+        return angle_axis(RGK_PI_F, axis);
+    }
+    f3 axis = cross3(start, dest);
+    float s = sqrtf((1 + cosTheta) * 2);
+    float invs = 1 / s;
+    quatf r; r.w = s * 0.5f; r.x = axis.x * invs; r.y = axis.y * invs; r.z = axis.z * invs;
+    return r;
+}
+// RotationFromY, reference src/glm.cpp:35-59
+__device__ inline quatf rotation_from_y(f3 dest) {
+    dest = norm3(dest);
+    float cosTheta = dest.y;
+    if (cosTheta < -1 + 0.00001f) return angle_axis(RGK_PI_F, mk3(1.0f, 0.0f, 0.0f));
+    f3 axis = cross3(mk3(0.0f, 1.0f, 0.0f), dest);
+    float s = sqrtf((1 + cosTheta) * 2);
+    float invs = 1 / s;
+    quatf r; r.w = s * 0.5f; r.x = axis.x * invs; r.y = axis.y * invs; r.z = axis.z * invs;
+    return r;
+}
+
+// ------------------------------------------------------------------ sampler (K0)
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float u01(uint32_t h) { return (float)(h >> 8) * (1.0f / 16777216.0f); }
+
+// HS::Halton_sampler::sample(dim, index) after init_faure(): reference
+// external/halton_sampler.h:627-889 (dispatch), :1418-.. (halton2, halton3, ...).
+// Digit walk with a per-base Faure permutation and a multiply-high division instead of
+// the header's 256 generated functions and grouped-digit tables; bit-identical results.
+__device__ inline float halton_raw(const DevScene& sc, uint32_t hdim, uint32_t index) {
+    if (hdim == 0) {
+        uint32_t u = 0x3f800000u | (__brev(index) >> 9);
+        return __uint_as_float(u) - 1.f;
+    }
+    const DevHaltonDim hd = sc.hdims[hdim];
+    uint32_t acc = 0, j = 0;
+    while (index != 0 && j < hd.digits) {
+        uint32_t t = __umulhi(hd.magic, index);
+        uint32_t q = (t + ((index - t) >> 1)) >> hd.shift;
+        uint32_t r = index - q * hd.base;
+        acc = acc * hd.base + (uint32_t)sc.hperm[hd.perm_off + r];
+        index = q;
+        j++;
+    }
+    for (; j < hd.digits; j++) acc *= hd.base; // sigma(0) == 0 for Faure permutations
+    return (float)acc * hd.scale;
+}
+__device__ __forceinline__ uint32_t hdim_key(uint32_t hdim) { return mix32(hdim * 0x9e3779b9u + 0x85ebca6bu); }
+__device__ inline float halton_cp(const DevScene& sc, uint32_t seed, uint32_t index, uint32_t hdim) {
+    if (hdim >= 192) return u01(mix32(mix32(seed ^ hdim_key(hdim)) + index * 0xc2b2ae35u));
+    float u = halton_raw(sc, hdim, index) + u01(mix32(seed ^ hdim_key(hdim)));
+    if (u >= 1.0f) u -= 1.0f;
+    return u;
+}
+// Sampler::Get2D / Get1D for logical dimension k of sample `index` (reference
+// src/sampler.cpp:26-36: separate 1-D and 2-D counters; 64 table dimensions each)
+__device__ inline float2 sample2d(const DevScene& sc, uint32_t seed, uint32_t index, uint32_t k) {
+    uint32_t d = k < 64 ? 3 * k : 192 + 3 * (k - 64);
+    float x = halton_cp(sc, seed, index, d);
+    float y = halton_cp(sc, seed, index, d + 1);
+    return make_float2(x, y);
+}
+__device__ inline float sample1d(const DevScene& sc, uint32_t seed, uint32_t index, uint32_t k) {
+    return halton_cp(sc, seed, index, k < 64 ? 3 * k + 2 : 192 + 3 * (k - 64) + 2);
+}
+
+// ------------------------------------------------------------------ random_utils.hpp:12-73
+__device__ inline float2 disc_uniform(float2 s) {
+    float r = sqrtf(s.x);
+    float a = (float)((double)(s.y * 2.0f) * 3.14159265358979323846);
+    return make_float2(r * sinf(a), r * cosf(a));
+}
+__device__ inline f3 hemisphere_cosine_z(float2 s) {
+    float2 p = disc_uniform(s);
+    float z = sqrtf(fmaxf(0.00001f, 1 - p.x * p.x - p.y * p.y));
+    return mk3(p.x, p.y, z);
+}
+__device__ inline f3 hemisphere_cosine_y(float2 s) {
+    float2 p = disc_uniform(s);
+    float y = sqrtf(fmaxf(0.00001f, 1 - p.x * p.x - p.y * p.y));
+    return mk3(p.x, y, p.y);
+}
+__device__ inline f3 sphere_uniform(float2 s) {
+    float z = s.x * 2.0f - 1.0f;
+    float a = (float)((double)s.y * 6.283185);
+    float r = sqrtf(1 - z * z);
+    return mk3(r * cosf(a), r * sinf(a), z);
+}
+__device__ __forceinline__ bool decide_and_rescale(float& sample, float probability) {
+    if (probability == 0.0f) return false;
+    if (probability == 1.0f) return true;
+    if (sample < probability) { sample /= probability; return true; }
+    sample = (sample - probability) / (1.0f - probability);
+    return false;
+}
+
+// ------------------------------------------------------------------ textures (a14)
+__device__ __forceinline__ float glm_repeat(float x) { return x - floorf(x); }
+__device__ __forceinline__ f3 texel_at(const DevScene& sc, const DevTexture& t, int idx) {
+    const float* p = sc.texels + t.offset + 3 * (size_t)idx;
+    return mk3(p[0], p[1], p[2]);
+}
+// ReadableTexture::GetPixelInterpolated, reference src/texture.cpp:35-77; id<0 = EmptyTexture
+__device__ inline f3 tex_get(const DevScene& sc, int id, float2 uv) {
+    if (id < 0) return mk3(0.f, 0.f, 0.f);
+    const DevTexture t = sc.textures[id];
+    if (t.kind == 0) return mk3(t.color[0], t.color[1], t.color[2]);
+    int xsize = (int)t.width, ysize = (int)t.height;
+    float x = glm_repeat(uv.x) * xsize - 0.5f;
+    float y = glm_repeat(uv.y) * ysize - 0.5f;
+    float ix0f = truncf(x), iy0f = truncf(y);
+    float fx = x - ix0f, fy = y - iy0f; // == std::modf fractional part (exact)
+    int ix0 = (int)ix0f, iy0 = (int)iy0f;
+    int ix1 = (ix0 != xsize - 1) ? ix0 + 1 : ix0;
+    int iy1 = (iy0 != ysize - 1) ? iy0 + 1 : iy0;
+    if (ix0 == -1) ix0 = 0;
+    if (iy0 == -1) iy0 = 0;
+    f3 c00 = texel_at(sc, t, iy0 * xsize + ix0), c01 = texel_at(sc, t, iy0 * xsize + ix1);
+    f3 c10 = texel_at(sc, t, iy1 * xsize + ix0), c11 = texel_at(sc, t, iy1 * xsize + ix1);
+    fy = 1.0f - fy;
+    fx = 1.0f - fx;
+    f3 c0s = fx * c00 + (1.0f - fx) * c01;
+    f3 c1s = fx * c10 + (1.0f - fx) * c11;
+    return fy * c0s + (1.0f - fy) * c1s;
+}
+// GetSlopeRight / GetSlopeBottom, reference src/texture.cpp:79-102
+__device__ inline void tex_slopes(const DevScene& sc, int id, float2 uv, float& right, float& bottom) {
+    right = 0.f; bottom = 0.f;
+    const DevTexture t = sc.textures[id];
+    if (t.kind == 0) return;
+    int xsize = (int)t.width, ysize = (int)t.height;
+    int x = (int)(glm_repeat(uv.x) * xsize - 0.5f);
+    int y = (int)(glm_repeat(uv.y) * ysize - 0.5f);
+    int x2 = (x != xsize - 1) ? x + 1 : x;
+    int y2 = (y != ysize - 1) ? y + 1 : y;
+    if (x == -1) x = 0;
+    if (y == -1) y = 0;
+    f3 here = texel_at(sc, t, y * xsize + x);
+    f3 tr = texel_at(sc, t, y * xsize + x2);
+    f3 tb = texel_at(sc, t, y2 * xsize + x);
+    float a = (here.x + here.y + here.z) / 3;
+    right = a - (tr.x + tr.y + tr.z) / 3;
+    bottom = a - (tb.x + tb.y + tb.z) / 3;
+}
+
+// ------------------------------------------------------------------ LTC (a12)
+// The fitted matrix has 5 live entries: M = [m0 0 m6; 0 m4 0; m2 0 m8] (rows), see
+// reference src/LTC/ltc.hpp:4-12 (column-major mat33 -> glm::mat3).
+struct LtcM {
+    float m0, m2, m4, m6, m8, amp;
+};
+// LTC::get_bilinear, reference src/LTC/ltc.cpp:20-57
+__device__ inline LtcM ltc_bilinear(const float* tab, float theta, float alpha) {
+    float t = fmaxf(0.0f, fminf(1.0f, theta / (0.5f * 3.14159f)));
+    float a = fmaxf(0.0f, fminf(1.0f, sqrtf(alpha)));
+    if (t >= 1.0f) t = 0.999f;
+    if (a >= 1.0f) a = 0.999f;
+    const int s = 63;
+    int t1 = (int)floorf(t * s), t2 = t1 + 1;
+    int a1 = (int)floorf(a * s), a2 = a1 + 1;
+    const float* e11 = tab + 5 * (a1 + t1 * 64);
+    const float* e12 = tab + 5 * (a2 + t1 * 64);
+    const float* e21 = tab + 5 * (a1 + t2 * 64);
+    const float* e22 = tab + 5 * (a2 + t2 * 64);
+    float dt1 = t * s - t1, dt2 = t2 - t * s, da1 = a * s - a1, da2 = a2 - a * s;
+#define RGK_BIL(k) (e11[k] * dt2 * da2 + e12[k] * dt2 * da1 + e21[k] * dt1 * da2 + e22[k] * dt1 * da1)
+    LtcM r;
+    r.m0 = RGK_BIL(0); r.m2 = RGK_BIL(1); r.m4 = RGK_BIL(2); r.m6 = RGK_BIL(3); r.amp = RGK_BIL(4);
+#undef RGK_BIL
+    r.m8 = 1.0f * dt2 * da2 + 1.0f * dt2 * da1 + 1.0f * dt1 * da2 + 1.0f * dt1 * da1;
+    return r;
+}
+// glm::determinant / glm::inverse restricted to the sparsity pattern; every surviving
+// product keeps its position in glm's cofactor expressions (x*0 and x-0 are exact).
+__device__ __forceinline__ float ltc_det(const LtcM& M) {
+    // m[0]=(m0,0,m2) m[1]=(0,m4,0) m[2]=(m6,0,m8)
+    float c00 = M.m4 * M.m8 - 0.0f * 0.0f;
+    float c20 = 0.0f * 0.0f - M.m4 * M.m2;
+    return +M.m0 * c00 - 0.0f * (0.0f * M.m8 - 0.0f * M.m2) + M.m6 * c20;
+}
+// LTC::GetPDF(ltc, N=+Z, Vr=A, Vi=B, alpha), reference src/LTC/ltc.cpp:59-87
+__device__ inline float ltc_pdf(const float* tab, f3 A, f3 B, float alpha) {
+    const f3 N = mk3(0.f, 0.f, 1.f);
+    f3 tangent = cross3(N, B);
+    f3 Bcast = cross3(tangent, N);
+    // rotate = mat3(Bcast, tangent, N); unrotate = inverse(rotate) (general glm formula)
+    float m00 = Bcast.x, m01 = Bcast.y, m02 = Bcast.z;
+    float m10 = tangent.x, m11 = tangent.y, m12 = tangent.z;
+    float m20 = N.x, m21 = N.y, m22 = N.z;
+    float ood = 1.0f / (+m00 * (m11 * m22 - m21 * m12) - m10 * (m01 * m22 - m21 * m02) + m20 * (m01 * m12 - m11 * m02));
+    float i00 = +(m11 * m22 - m21 * m12) * ood, i10 = -(m10 * m22 - m20 * m12) * ood, i20 = +(m10 * m21 - m20 * m11) * ood;
+    float i01 = -(m01 * m22 - m21 * m02) * ood, i11 = +(m00 * m22 - m20 * m02) * ood, i21 = -(m00 * m21 - m20 * m01) * ood;
+    float i02 = +(m01 * m12 - m11 * m02) * ood, i12 = -(m00 * m12 - m10 * m02) * ood, i22 = +(m00 * m11 - m10 * m01) * ood;
+    f3 A3 = mk3(i00 * A.x + i10 * A.y + i20 * A.z, i01 * A.x + i11 * A.y + i21 * A.z, i02 * A.x + i12 * A.y + i22 * A.z);
+    float theta = glm_angle(B, N);
+    LtcM M = ltc_bilinear(tab, theta, alpha);
+    // invM = glm::inverse(M) with m[0]=(m0,0,m2) m[1]=(0,m4,0) m[2]=(m6,0,m8)
+    float a00 = M.m0, a02 = M.m2, a11 = M.m4, a20 = M.m6, a22 = M.m8;
+    float oodM = 1.0f / (+a00 * (a11 * a22 - 0.0f * 0.0f) - 0.0f * (0.0f * a22 - 0.0f * a02) + a20 * (0.0f * 0.0f - a11 * a02));
+    float j00 = +(a11 * a22 - 0.0f * 0.0f) * oodM, j10 = -(0.0f * a22 - a20 * 0.0f) * oodM, j20 = +(0.0f * 0.0f - a20 * a11) * oodM;
+    float j01 = -(0.0f * a22 - 0.0f * a02) * oodM, j11 = +(a00 * a22 - a20 * a02) * oodM, j21 = -(a00 * 0.0f - a20 * 0.0f) * oodM;
+    float j02 = +(0.0f * 0.0f - a11 * a02) * oodM, j12 = -(a00 * 0.0f - 0.0f * a02) * oodM, j22 = +(a00 * a11 - 0.0f * 0.0f) * oodM;
+    f3 p = norm3(mk3(j00 * A3.x + j10 * A3.y + j20 * A3.z, j01 * A3.x + j11 * A3.y + j21 * A3.z, j02 * A3.x + j12 * A3.y + j22 * A3.z));
+    // L_ = M * p
+    f3 L = mk3(a00 * p.x + 0.0f * p.y + a20 * p.z, 0.0f * p.x + a11 * p.y + 0.0f * p.z, a02 * p.x + 0.0f * p.y + a22 * p.z);
+    float l = len3(L);
+    float detM = ltc_det(M);
+    float Jacobian = detM / (l * l * l);
+    float D = 1.0f / 3.14159f * fmaxf(0.0f, p.z);
+    return M.amp * D / Jacobian;
+}
+// LTC::GetRandom(ltc, N=+Z, Vi, roughness, rand_hscos), reference src/LTC/ltc.cpp:113-143
+__device__ inline f3 ltc_random(const float* tab, f3 Vi, float roughness, f3 rnd) {
+    const f3 N = mk3(0.f, 0.f, 1.f);
+    f3 tangent = cross3(N, Vi);
+    f3 Vc = cross3(tangent, N);
+    float theta = glm_angle(Vi, N);
+    LtcM M = ltc_bilinear(tab, fmaxf(theta, RGK_PI_F / 4.0f), roughness);
+    f3 s = mk3(M.m0 * rnd.x + 0.0f * rnd.y + M.m6 * rnd.z, 0.0f * rnd.x + M.m4 * rnd.y + 0.0f * rnd.z,
+               M.m2 * rnd.x + 0.0f * rnd.y + M.m8 * rnd.z);
+    if (s.z < 0.0001f) s.z = 0.0001f;
+    f3 r = mk3(Vc.x * s.x + tangent.x * s.y + N.x * s.z, Vc.y * s.x + tangent.y * s.y + N.y * s.z,
+               Vc.z * s.x + tangent.z * s.y + N.z * s.z);
+    return norm3(r);
+}
+
+// ------------------------------------------------------------------ BxDFs (a11)
+// FresnellDielectric, reference src/bxdf/bxdf.cpp:332-355
+__device__ inline void fresnel_dielectric(float eta, float cosTheta, float& R, float& cosT) {
+    if (cosTheta < 0.0f) { eta = 1.0f / eta; cosTheta = -cosTheta; }
+    float sinThetaTSq = eta * eta * (1.0f - cosTheta * cosTheta);
+    if (sinThetaTSq > 1.0f) { R = 1.0f; cosT = 0.0f; return; }
+    float cosThetaTrans = sqrtf(fmaxf(1.0f - sinThetaTSq, 0.0f));
+    float Rs = (eta * cosTheta - cosThetaTrans) / (eta * cosTheta + cosThetaTrans);
+    float Rp = (eta * cosThetaTrans - cosTheta) / (eta * cosThetaTrans + cosTheta);
+    R = 0.5f * (Rs * Rs + Rp * Rp);
+    cosT = cosThetaTrans;
+}
+
+// BxDF::value of a non-mix material, reference src/bxdf/bxdf.cpp:192-423, bxdf.hpp:107-159
+__device__ inline f3 bxdf_value_leaf(const DevScene& sc, const DevMaterial& m, f3 Vi, f3 Vr, float2 uv) {
+    const f3 zero = mk3(0.f, 0.f, 0.f);
+    switch (m.kind) {
+    case RGK_BXDF_DIFFUSE:
+        if (Vi.z <= 0 || Vr.z <= 0) return zero;
+        return tex_get(sc, m.tex_diffuse, uv) / RGK_PI_F;
+    case RGK_BXDF_MIRROR: {
+        f3 refl = mk3(-Vi.x, -Vi.y, Vi.z);
+        return (fabsf(dot3(refl, Vr) - 1) < 0.0001f) ? tex_get(sc, m.tex_color, uv) : zero;
+    }
+    case RGK_BXDF_DIELECTRIC: {
+        float eta = (Vi.z < 0) ? m.ior : (float)(1.0 / (double)m.ior);
+        float R, cosT;
+        fresnel_dielectric(eta, Vi.z, R, cosT);
+        f3 c = tex_get(sc, m.tex_color, uv);
+        if (Vi.z * Vr.z > 0) {
+            f3 refl = mk3(-Vi.x, -Vi.y, Vi.z);
+            return (fabsf(dot3(Vr, refl) - 1) < 0.001f) ? mk3(R, R, R) * c : zero;
+        }
+        f3 refr = mk3(-Vi.x * eta, -Vi.y * eta, (Vi.z > 0) ? -cosT : cosT);
+        float T = 1.0f - R;
+        return (fabsf(dot3(Vr, refr) - 1) < 0.001f) ? mk3(T, T, T) * c : zero;
+    }
+    case RGK_BXDF_TRANSPARENT: {
+        f3 inv = mk3(-Vi.x, -Vi.y, -Vi.z);
+        return (fabsf(dot3(inv, Vr) - 1) < 0.0001f) ? mk3(1.f, 1.f, 1.f) : zero;
+    }
+    case RGK_BXDF_LTC_BECKMANN:
+    case RGK_BXDF_LTC_GGX: {
+        if (Vi.z <= 0 || Vr.z <= 0) return zero;
+        const float* tab = (m.kind == RGK_BXDF_LTC_GGX) ? sc.ltc_ggx : sc.ltc_beckmann;
+        return tex_get(sc, m.tex_color, uv) * ltc_pdf(tab, Vi, Vr, m.roughness);
+    }
+    case RGK_BXDF_LTC_BECKMANN_DIFFUSE:
+    case RGK_BXDF_LTC_GGX_DIFFUSE: {
+        if (Vi.z <= 0 || Vr.z <= 0) return zero;
+        const float* tab = (m.kind == RGK_BXDF_LTC_GGX_DIFFUSE) ? sc.ltc_ggx : sc.ltc_beckmann;
+        f3 diff = tex_get(sc, m.tex_diffuse, uv);
+        f3 spec = tex_get(sc, m.tex_color, uv);
+        return spec * ltc_pdf(tab, Vi, Vr, m.roughness) + diff / RGK_PI_F;
+    }
+    default: return zero;
+    }
+}
+// BxDFMix::value recurses once per level (reference bxdf.cpp:235-239); the device walks an
+// explicit stack so nested mixes up to 4 deep are evaluated without recursion.
+__device__ inline f3 bxdf_value(const DevScene& sc, int mat, f3 Vi, f3 Vr, float2 uv) {
+    const DevMaterial m = sc.materials[mat];
+    if (m.kind != RGK_BXDF_MIX) return bxdf_value_leaf(sc, m, Vi, Vr, uv);
+    // s1*amt1 + s2*(1-amt1) with one nested level on either side
+    f3 s[2];
+    const int ch[2] = {m.mix_m1, m.mix_m2};
+    for (int k = 0; k < 2; k++) {
+        const DevMaterial c = sc.materials[ch[k]];
+        if (c.kind != RGK_BXDF_MIX) s[k] = bxdf_value_leaf(sc, c, Vi, Vr, uv);
+        else {
+            const DevMaterial c1 = sc.materials[c.mix_m1];
+            const DevMaterial c2 = sc.materials[c.mix_m2];
+            f3 v1 = (c1.kind == RGK_BXDF_MIX) ? mk3(0.f, 0.f, 0.f) : bxdf_value_leaf(sc, c1, Vi, Vr, uv);
+            f3 v2 = (c2.kind == RGK_BXDF_MIX) ? mk3(0.f, 0.f, 0.f) : bxdf_value_leaf(sc, c2, Vi, Vr, uv);
+            s[k] = v1 * c.amount + v2 * (1.0f - c.amount);
+        }
+    }
+    return s[0] * m.amount + s[1] * (1.0f - m.amount);
+}
+
+// BxDF::sample, reference src/bxdf/bxdf.cpp:197-204,241-249,272-276,378-408,419-423, bxdf.hpp:115-159
+__device__ inline void bxdf_sample(const DevScene& sc, int mat, f3 Vi, float2 uv, float2 u, f3& dir, f3& weight, bool& may_leak) {
+    DevMaterial m = sc.materials[mat];
+    for (int lvl = 0; lvl < 8 && m.kind == RGK_BXDF_MIX; lvl++) // BxDFMix::sample descends one side
+        m = sc.materials[decide_and_rescale(u.x, m.amount) ? m.mix_m1 : m.mix_m2];
+    may_leak = false;
+    const f3 zero = mk3(0.f, 0.f, 0.f);
+    switch (m.kind) {
+    case RGK_BXDF_DIFFUSE:
+        if (Vi.z <= 0) { dir = mk3(0.f, 1.f, 0.f); weight = zero; return; }
+        dir = hemisphere_cosine_z(u);
+        weight = tex_get(sc, m.tex_diffuse, uv);
+        return;
+    case RGK_BXDF_MIRROR:
+        dir = mk3(-Vi.x, -Vi.y, Vi.z);
+        weight = tex_get(sc, m.tex_color, uv);
+        return;
+    case RGK_BXDF_DIELECTRIC: {
+        float eta = (Vi.z < 0) ? m.ior : (float)(1.0 / (double)m.ior);
+        float R, cosT;
+        fresnel_dielectric(eta, fabsf(Vi.z), R, cosT);
+        weight = tex_get(sc, m.tex_color, uv);
+        if (decide_and_rescale(u.x, R)) { dir = mk3(-Vi.x, -Vi.y, Vi.z); return; }
+        cosT = fabsf(cosT);
+        dir = mk3(-Vi.x * eta, -Vi.y * eta, (Vi.z > 0) ? -cosT : cosT);
+        may_leak = true;
+        return;
+    }
+    case RGK_BXDF_TRANSPARENT:
+        dir = mk3(-Vi.x, -Vi.y, -Vi.z);
+        weight = mk3(1.f, 1.f, 1.f);
+        may_leak = true;
+        return;
+    case RGK_BXDF_LTC_BECKMANN:
+    case RGK_BXDF_LTC_GGX: {
+        const float* tab = (m.kind == RGK_BXDF_LTC_GGX) ? sc.ltc_ggx : sc.ltc_beckmann;
+        f3 v = ltc_random(tab, Vi, m.roughness, hemisphere_cosine_z(u));
+        dir = v;
+        weight = (v.z <= 0) ? zero : tex_get(sc, m.tex_color, uv);
+        return;
+    }
+    case RGK_BXDF_LTC_BECKMANN_DIFFUSE:
+    case RGK_BXDF_LTC_GGX_DIFFUSE: {
+        const float* tab = (m.kind == RGK_BXDF_LTC_GGX_DIFFUSE) ? sc.ltc_ggx : sc.ltc_beckmann;
+        f3 diff = tex_get(sc, m.tex_diffuse, uv);
+        f3 spec = tex_get(sc, m.tex_color, uv);
+        float dp = diff.x + diff.y + diff.z, sp = spec.x + spec.y + spec.z;
+        float prob = dp / (dp + sp + 0.0001f);
+        if (decide_and_rescale(u.x, prob)) {
+            if (Vi.z <= 0) { dir = mk3(0.f, 1.f, 0.f); weight = zero; return; }
+            dir = hemisphere_cosine_z(u);
+            weight = diff;
+            return;
+        }
+        f3 v = ltc_random(tab, Vi, m.roughness, hemisphere_cosine_z(u));
+        dir = v;
+        weight = (v.z <= 0) ? zero : spec;
+        return;
+    }
+    default:
+        dir = mk3(0.f, 1.f, 0.f);
+        weight = zero;
+    }
+}
+
+// ------------------------------------------------------------------ lights / sky (a10, a15)
+struct DLight {
+    f3 pos, color, normal;
+    float intensity, size;
+    int type; // 0 FULL_SPHERE, 1 HEMISPHERE, -1 none (Q15: zero contribution)
+};
+__device__ __forceinline__ float light_dir_factor(const DLight& l, f3 v) {
+    return l.type == 0 ? 1.0f : fmaxf(0.0f, dot3(v, l.normal));
+}
+// Scene::GetRandomLight + ArealLight::GetRandomLight + Triangle::GetRandomPoint, reference
+// src/scene.cpp:686-745, src/primitives.cpp:61-73
+__device__ inline DLight random_light(const DevScene& sc, float2 choice, float light_sample, float2 tri_sample) {
+    DLight L;
+    L.type = -1;
+    L.pos = L.color = L.normal = mk3(0.f, 0.f, 0.f);
+    L.intensity = 0.f; L.size = 0.f;
+    float total_power = sc.total_point_power + sc.total_areal_power;
+    if (total_power <= 0.0f) return L;
+    float q = choice.x * total_power;
+    if (q < sc.total_point_power) {
+        for (uint32_t i = 0; i < sc.n_pointlights; i++) {
+            const DevPointLight pl = sc.pointlights[i];
+            q -= pl.intensity * 4.0f * RGK_PI_F;
+            if (q <= 0.0f) {
+                L.type = 0;
+                L.pos = mk3(pl.pos[0], pl.pos[1], pl.pos[2]);
+                L.color = mk3(pl.color[0], pl.color[1], pl.color[2]);
+                L.intensity = pl.intensity; L.size = pl.size;
+                return L;
+            }
+        }
+        return L;
+    }
+    q = choice.y * sc.total_areal_power;
+    for (uint32_t i = 0; i < sc.n_areal; i++) {
+        const DevArealLight al = sc.areal[i];
+        q -= al.power;
+        if (q <= 0.0f) {
+            float p = light_sample * al.total_area;
+            for (uint32_t j = 0; j < al.count; j++) {
+                const DevArealTri* at = &sc.areal_tris[al.first + j];
+                p -= at->area;
+                if (p <= 0.0f) {
+                    float2 r = tri_sample;
+                    f3 a = mk3(at->a[0], at->a[1], at->a[2]);
+                    f3 c = mk3(at->b[0], at->b[1], at->b[2]);
+                    f3 b = mk3(at->c[0], at->c[1], at->c[2]);
+                    f3 Va = a - c, Vb = b - c;
+                    if (r.x + r.y > 1.0f) { r.x = 1.0f - r.x; r.y = 1.0f - r.y; }
+                    L.type = 1;
+                    L.pos = c + r.x * Va + r.y * Vb;
+                    L.color = mk3(al.emission[0], al.emission[1], al.emission[2]);
+                    L.intensity = 1.0f;
+                    L.normal = mk3(at->normal_a[0], at->normal_a[1], at->normal_a[2]);
+                    return L;
+                }
+            }
+            return L;
+        }
+    }
+    return L;
+}
+// Scene::GetSkyboxRay, reference src/scene.cpp:748-763
+__device__ inline f3 skybox(const DevScene& sc, f3 direction) {
+    if (sc.sky_mode == 0) return mk3(sc.sky_color[0], sc.sky_color[1], sc.sky_color[2]) * mk3(sc.sky_intensity, sc.sky_intensity, sc.sky_intensity);
+    float alpha = asinf(direction.y);
+    float beta = -atan2f(direction.x, direction.z);
+    beta += sc.sky_rotate * 0.0174533f;
+    float x = beta / (2.0f * RGK_PI_F) + 0.5f;
+    float y = alpha / RGK_PI_F + 0.5f;
+    f3 c = tex_get(sc, sc.sky_texture, make_float2(x, y));
+    return c * mk3(sc.sky_intensity, sc.sky_intensity, sc.sky_intensity);
+}

@@ -1,0 +1,855 @@
+// Host runtime behind the C ABI of include/rgk.h.
+//
+//   * scene commit: the OUTPUTS of Scene::Commit the hot path reads (reference
+//     src/scene.cpp:294-400): triangle planes, areal-light tables sorted by area,
+//     light powers, epsilon = 1e-5 * bbox diagonal, epsilon-padded bbox;
+//   * the build's own accelerator (binned-SAH BVH2, 64-byte nodes) -- the reference's
+//     kd-tree construction (scene.cpp:431-657) is out of scope, only its nearest-hit
+//     semantics are kept;
+//   * the round driver: tiles -> per-pixel seeds (a2) -> passes of paths resident in
+//     HBM -> raygen / trace / shade / shadow / resolve launches on one HIP stream.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/rgk.h"
+#include "device_types.h"
+#include "rgk_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(x)                                                                                     \
+    do {                                                                                              \
+        hipError_t e_ = (x);                                                                          \
+        if (e_ != hipSuccess)                                                                         \
+            return fail(e_ == hipErrorOutOfMemory ? RGK_ERR_OOM : RGK_ERR_DEVICE, "%s: %s (%s:%d)", #x, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                   \
+    } while (0)
+
+struct V3 {
+    float x, y, z;
+};
+inline V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 crossv(V3 x, V3 y) { return {x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y}; }
+inline float dotv(V3 a, V3 b) {
+    float tx = a.x * b.x, ty = a.y * b.y, tz = a.z * b.z;
+    return tx + ty + tz;
+}
+inline V3 scale(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline V3 normv(V3 v) { return scale(v, 1.0f / std::sqrt(dotv(v, v))); }
+inline float comp(V3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
+
+// ------------------------------------------------------------------ BVH build
+struct Prim {
+    float bmin[3], bmax[3], c[3];
+    uint32_t tri;
+};
+struct Box {
+    float mn[3], mx[3];
+    void reset() { for (int i = 0; i < 3; i++) { mn[i] = std::numeric_limits<float>::infinity(); mx[i] = -mn[i]; } }
+    void grow(const float* a, const float* b) { for (int i = 0; i < 3; i++) { mn[i] = std::min(mn[i], a[i]); mx[i] = std::max(mx[i], b[i]); } }
+    void grow(const Box& o) { grow(o.mn, o.mx); }
+    float area() const {
+        float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+        if (dx < 0 || dy < 0 || dz < 0) return 0.f;
+        return 2.f * (dx * dy + dy * dz + dz * dx);
+    }
+};
+
+struct BvhBuilder {
+    std::vector<Prim>& prims;
+    std::vector<BvhNode> nodes;
+    std::vector<uint32_t> order; // triangle ids in leaf order
+    uint32_t max_depth = 0;
+    float pad;
+    static constexpr int NBINS = 16;
+    static constexpr int MAX_LEAF = 4;
+    static constexpr float C_TRAV = 1.0f, C_ISECT = 2.0f;
+    BvhBuilder(std::vector<Prim>& p, float pad_) : prims(p), pad(pad_) {}
+
+    int make_leaf(size_t b, size_t e) {
+        uint32_t first = order.size();
+        for (size_t i = b; i < e; i++) order.push_back(prims[i].tri);
+        uint32_t cnt = (uint32_t)(e - b);
+        return (int)~((first << 4) | (cnt - 1));
+    }
+    // returns the child code for prims[b,e) and its (padded) box
+    int build(size_t b, size_t e, uint32_t depth, Box& box) {
+        max_depth = std::max(max_depth, depth);
+        box.reset();
+        Box cb;
+        cb.reset();
+        for (size_t i = b; i < e; i++) { box.grow(prims[i].bmin, prims[i].bmax); cb.grow(prims[i].c, prims[i].c); }
+        size_t n = e - b;
+        size_t mid = 0;
+        bool leaf = (n == 1);
+        if (!leaf) {
+            float best = std::numeric_limits<float>::infinity();
+            int best_axis = -1, best_bin = -1;
+            float parent_area = box.area();
+            for (int ax = 0; ax < 3; ax++) {
+                float lo = cb.mn[ax], hi = cb.mx[ax];
+                if (!(hi > lo)) continue;
+                Box bb[NBINS];
+                uint32_t cnt[NBINS] = {0};
+                for (auto& x : bb) x.reset();
+                float k = NBINS / (hi - lo);
+                for (size_t i = b; i < e; i++) {
+                    int bi = std::min(NBINS - 1, std::max(0, (int)((prims[i].c[ax] - lo) * k)));
+                    cnt[bi]++;
+                    bb[bi].grow(prims[i].bmin, prims[i].bmax);
+                }
+                float ra[NBINS];
+                uint32_t rc[NBINS];
+                Box acc;
+                acc.reset();
+                uint32_t c = 0;
+                for (int i = NBINS - 1; i > 0; i--) { acc.grow(bb[i]); c += cnt[i]; ra[i] = acc.area(); rc[i] = c; }
+                acc.reset();
+                c = 0;
+                for (int i = 0; i < NBINS - 1; i++) {
+                    acc.grow(bb[i]);
+                    c += cnt[i];
+                    if (c == 0 || rc[i + 1] == 0) continue;
+                    float cost = C_TRAV + C_ISECT * (acc.area() * c + ra[i + 1] * rc[i + 1]) / std::max(parent_area, 1e-30f);
+                    if (cost < best) { best = cost; best_axis = ax; best_bin = i; }
+                }
+            }
+            if (best_axis >= 0 && (n > (size_t)MAX_LEAF || best < C_ISECT * n)) {
+                float lo = cb.mn[best_axis], hi = cb.mx[best_axis];
+                float k = NBINS / (hi - lo);
+                auto it = std::partition(prims.begin() + b, prims.begin() + e, [&](const Prim& p) {
+                    int bi = std::min(NBINS - 1, std::max(0, (int)((p.c[best_axis] - lo) * k)));
+                    return bi <= best_bin;
+                });
+                mid = it - prims.begin();
+                if (mid == b || mid == e) best_axis = -1;
+            } else if (best_axis >= 0) {
+                leaf = true; // SAH prefers a leaf and it fits
+                best_axis = 0;
+            }
+            if (!leaf && best_axis < 0) {
+                if (n <= (size_t)MAX_LEAF) leaf = true;
+                else { // coincident centroids: median split by index
+                    int ax = 0;
+                    float ex = -1;
+                    for (int a = 0; a < 3; a++) if (box.mx[a] - box.mn[a] > ex) { ex = box.mx[a] - box.mn[a]; ax = a; }
+                    mid = b + n / 2;
+                    std::nth_element(prims.begin() + b, prims.begin() + mid, prims.begin() + e,
+                                     [ax](const Prim& p, const Prim& q) { return p.c[ax] < q.c[ax]; });
+                }
+            }
+        }
+        for (int i = 0; i < 3; i++) { box.mn[i] -= pad; box.mx[i] += pad; }
+        if (leaf) return make_leaf(b, e);
+        int idx = (int)nodes.size();
+        nodes.emplace_back();
+        Box lb, rb;
+        int l = build(b, mid, depth + 1, lb);
+        int r = build(mid, e, depth + 1, rb);
+        BvhNode& nd = nodes[idx];
+        for (int i = 0; i < 3; i++) { nd.lmin[i] = lb.mn[i]; nd.lmax[i] = lb.mx[i]; nd.rmin[i] = rb.mn[i]; nd.rmax[i] = rb.mx[i]; }
+        nd.left = l; nd.right = r; nd.pad[0] = nd.pad[1] = 0;
+        return idx;
+    }
+};
+
+// ------------------------------------------------------------------ scene object
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    int alloc(size_t count) {
+        if (count <= n && p) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        if (e != hipSuccess) return fail(RGK_ERR_OOM, "hipMalloc(%zu bytes): %s", count * sizeof(T), hipGetErrorString(e));
+        n = count;
+        return 0;
+    }
+    int upload(const std::vector<T>& v) {
+        int rc = alloc(v.size());
+        if (rc) return rc;
+        if (!v.empty()) {
+            hipError_t e = hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+            if (e != hipSuccess) return fail(RGK_ERR_DEVICE, "hipMemcpy H2D: %s", hipGetErrorString(e));
+        }
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+} // namespace
+
+struct rgk_scene {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    rgk_scene_info info{};
+    DevScene dev{};
+    int stack = 32;
+    // scene data
+    DevBuf<BvhNode> nodes;
+    DevBuf<TriIsect> tris;
+    DevBuf<TriShade> tri_shade;
+    DevBuf<VtxAttr> vtx;
+    DevBuf<DevMaterial> materials;
+    DevBuf<DevTexture> textures;
+    DevBuf<float> texels;
+    DevBuf<DevPointLight> pointlights;
+    DevBuf<DevArealLight> areal;
+    DevBuf<DevArealTri> areal_tris;
+    DevBuf<float> ltc_ggx, ltc_beckmann;
+    DevBuf<DevHaltonDim> hdims;
+    DevBuf<uint16_t> hperm;
+    // workspace
+    size_t batch = 0;
+    DevBuf<float4> rayA[2], rayB[2], hit, thr, tot, shA, shB, shC, pixsum;
+    DevBuf<float2> nearfar;
+    DevBuf<uint32_t> counters, pix_xy, pix_seed;
+    DevBuf<unsigned long long> stats;
+    DevBuf<float> scratch_f;
+    DevBuf<uint32_t> scratch_u;
+    std::vector<hipEvent_t> events;
+    uint32_t* h_counters = nullptr; // pinned
+    ~rgk_scene() {
+        (void)hipSetDevice(device);
+        for (auto e : events) (void)hipEventDestroy(e);
+        if (h_counters) (void)hipHostFree(h_counters);
+        nodes.release(); tris.release(); tri_shade.release(); vtx.release(); materials.release(); textures.release();
+        texels.release(); pointlights.release(); areal.release(); areal_tris.release(); ltc_ggx.release();
+        ltc_beckmann.release(); hdims.release(); hperm.release();
+        for (int i = 0; i < 2; i++) { rayA[i].release(); rayB[i].release(); }
+        hit.release(); thr.release(); tot.release(); shA.release(); shB.release(); shC.release(); pixsum.release();
+        nearfar.release(); counters.release(); pix_xy.release(); pix_seed.release(); stats.release();
+        scratch_f.release(); scratch_u.release();
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+int ensure_workspace(rgk_scene* s, size_t paths) {
+    if (paths <= s->batch) return 0;
+    int rc = 0;
+    for (int i = 0; i < 2 && !rc; i++) { rc = s->rayA[i].alloc(paths); if (!rc) rc = s->rayB[i].alloc(paths); }
+    if (!rc) rc = s->hit.alloc(paths);
+    if (!rc) rc = s->thr.alloc(paths);
+    if (!rc) rc = s->tot.alloc(paths);
+    if (!rc) rc = s->shA.alloc(paths);
+    if (!rc) rc = s->shB.alloc(paths);
+    if (!rc) rc = s->shC.alloc(paths);
+    if (!rc) rc = s->counters.alloc(RGK_CNT_TOTAL);
+    if (!rc) rc = s->stats.alloc(8);
+    if (rc) return rc;
+    if (!s->h_counters) HIPCHK(hipHostMalloc((void**)&s->h_counters, RGK_CNT_TOTAL * sizeof(uint32_t)));
+    s->batch = paths;
+    return 0;
+}
+
+void build_halton(std::vector<DevHaltonDim>& dims, std::vector<uint16_t>& perm) {
+    // Faure permutations: the standard recursive construction the reference uses
+    // (external/halton_sampler.h:574-604), one permutation per prime base.
+    const unsigned max_base = 1619u;
+    std::vector<std::vector<uint16_t>> perms(max_base + 1);
+    for (unsigned k = 1; k <= 3; ++k) { perms[k].resize(k); for (unsigned i = 0; i < k; ++i) perms[k][i] = i; }
+    for (unsigned base = 4; base <= max_base; ++base) {
+        perms[base].resize(base);
+        unsigned b = base / 2;
+        if (base & 1) {
+            for (unsigned i = 0; i + 1 < base; ++i) {
+                uint16_t v = perms[base - 1][i];
+                perms[base][i + (i >= b)] = v + (v >= b);
+            }
+            perms[base][b] = b;
+        } else {
+            for (unsigned i = 0; i < b; ++i) { perms[base][i] = 2 * perms[b][i]; perms[base][b + i] = 2 * perms[b][i] + 1; }
+        }
+    }
+    for (unsigned p = 2; dims.size() < 256; p++) {
+        bool prime = true;
+        for (unsigned d = 2; d * d <= p; d++) if (p % d == 0) { prime = false; break; }
+        if (!prime) continue;
+        DevHaltonDim hd{};
+        hd.base = p;
+        uint64_t bk = p; unsigned k = 1;
+        while (bk * p <= 500) { bk *= p; k++; }  // digits per table lookup in the reference
+        uint64_t tot = bk; unsigned G = 1;
+        while (tot * bk < (1ull << 32)) { tot *= bk; G++; } // lookups per sample
+        hd.digits = k * G;
+        hd.scale = float(0x1.fffffcp-1 / (double)tot);
+        hd.perm_off = (uint32_t)perm.size();
+        if (p > 2) { // exact u32 division by p: q = (t + ((n - t) >> 1)) >> (l - 1), t = mulhi(m, n)
+            unsigned l = 0;
+            while ((1u << l) < p) l++;
+            hd.magic = (uint32_t)(((1ull << 32) * ((1ull << l) - p)) / p + 1);
+            hd.shift = l - 1;
+        }
+        perm.insert(perm.end(), perms[p].begin(), perms[p].end());
+        dims.push_back(hd);
+    }
+}
+
+int validate_desc(const rgk_scene_desc* d) {
+    if (!d) return fail(RGK_ERR_INVALID, "null scene descriptor");
+    if (d->n_triangles == 0 || d->n_vertices == 0) return fail(RGK_ERR_INVALID, "scene has no geometry");
+    if (!d->vertices || !d->normals || !d->tangents || !d->tri_indices || !d->tri_material)
+        return fail(RGK_ERR_INVALID, "null geometry pointer");
+    if (d->n_materials == 0 || !d->materials) return fail(RGK_ERR_INVALID, "scene has no materials");
+    for (uint32_t i = 0; i < d->n_triangles; i++) {
+        for (int k = 0; k < 3; k++)
+            if (d->tri_indices[3 * i + k] >= d->n_vertices) return fail(RGK_ERR_INVALID, "triangle %u: vertex index out of range", i);
+        if (d->tri_material[i] >= d->n_materials) return fail(RGK_ERR_INVALID, "triangle %u: material index out of range", i);
+    }
+    bool ggx = false, bek = false;
+    for (uint32_t i = 0; i < d->n_materials; i++) {
+        const rgk_material& m = d->materials[i];
+        if (m.kind > RGK_BXDF_LTC_GGX_DIFFUSE) return fail(RGK_ERR_INVALID, "material %u: unknown bxdf kind %u", i, m.kind);
+        const int32_t t[3] = {m.tex_diffuse, m.tex_color, m.tex_bump};
+        for (int k = 0; k < 3; k++)
+            if (t[k] >= (int32_t)d->n_textures) return fail(RGK_ERR_INVALID, "material %u: texture index out of range", i);
+        if (m.kind == RGK_BXDF_MIX && (m.mix_m1 < 0 || m.mix_m2 < 0 || m.mix_m1 >= (int32_t)d->n_materials || m.mix_m2 >= (int32_t)d->n_materials))
+            return fail(RGK_ERR_INVALID, "material %u: mix children out of range", i);
+        if (m.kind == RGK_BXDF_LTC_GGX || m.kind == RGK_BXDF_LTC_GGX_DIFFUSE) ggx = true;
+        if (m.kind == RGK_BXDF_LTC_BECKMANN || m.kind == RGK_BXDF_LTC_BECKMANN_DIFFUSE) bek = true;
+    }
+    if (ggx && !d->ltc_ggx) return fail(RGK_ERR_INVALID, "LTC GGX material without ltc_ggx table");
+    if (bek && !d->ltc_beckmann) return fail(RGK_ERR_INVALID, "LTC Beckmann material without ltc_beckmann table");
+    for (uint32_t i = 0; i < d->n_textures; i++) {
+        const rgk_texture& t = d->textures[i];
+        if (t.kind == RGK_TEX_RGB32F && (!t.texels || t.width == 0 || t.height == 0)) return fail(RGK_ERR_INVALID, "texture %u: empty image", i);
+        if (t.kind > RGK_TEX_RGB32F) return fail(RGK_ERR_INVALID, "texture %u: unknown kind", i);
+    }
+    for (uint32_t i = 0; i < d->n_areal_lights; i++)
+        for (uint32_t j = d->areal_offsets[i]; j < d->areal_offsets[i + 1]; j++)
+            if (d->areal_tris[j] >= d->n_triangles) return fail(RGK_ERR_INVALID, "areal light %u: triangle out of range", i);
+    if (d->sky_mode == RGK_SKY_ENVMAP && (d->sky_texture < 0 || d->sky_texture >= (int32_t)d->n_textures))
+        return fail(RGK_ERR_INVALID, "sky envmap texture out of range");
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* rgk_last_error(void) { return g_err.c_str(); }
+
+int rgk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
+    if (!out) return fail(RGK_ERR_INVALID, "null output pointer");
+    *out = nullptr;
+    int rc = validate_desc(d);
+    if (rc) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(RGK_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(RGK_ERR_INVALID, "device %d out of range (%d visible)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    rgk_scene* s = new rgk_scene;
+    s->device = device;
+    struct Guard { rgk_scene* s; ~Guard() { delete s; } } guard{s};
+    HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+
+    const uint32_t nt = d->n_triangles, nv = d->n_vertices;
+    auto vert = [&](uint32_t i) { return V3{d->vertices[3 * i], d->vertices[3 * i + 1], d->vertices[3 * i + 2]}; };
+
+    // ---- Commit: bounds, epsilon (scene.cpp:364-395)
+    float mn[3], mx[3];
+    for (int a = 0; a < 3; a++) { mn[a] = std::numeric_limits<float>::infinity(); mx[a] = -mn[a]; }
+    for (uint32_t i = 0; i < nt; i++)
+        for (int k = 0; k < 3; k++) {
+            V3 v = vert(d->tri_indices[3 * i + k]);
+            for (int a = 0; a < 3; a++) { float c = comp(v, a); if (c < mn[a]) mn[a] = c; if (c > mx[a]) mx[a] = c; }
+        }
+    float xs = mx[0] - mn[0], ys = mx[1] - mn[1], zs = mx[2] - mn[2];
+    float diameter = std::sqrt(xs * xs + ys * ys + zs * zs);
+    float eps = 0.00001f * diameter;
+    if (!(eps == eps) || !(diameter < std::numeric_limits<float>::infinity())) return fail(RGK_ERR_INVALID, "non-finite vertex coordinates");
+    DevScene& ds = s->dev;
+    ds.epsilon = eps;
+    for (int a = 0; a < 3; a++) { ds.bb_min[a] = mn[a] - eps; ds.bb_max[a] = mx[a] + eps; }
+
+    // ---- planes + intersection records (primitives.cpp:24-36, 75-166)
+    std::vector<TriIsect> recs(nt);
+    std::vector<Prim> prims;
+    prims.reserve(nt);
+    for (uint32_t i = 0; i < nt; i++) {
+        V3 v0 = vert(d->tri_indices[3 * i]), v1 = vert(d->tri_indices[3 * i + 1]), v2 = vert(d->tri_indices[3 * i + 2]);
+        V3 d0 = sub(v1, v0), d1 = sub(v2, v0);
+        V3 n = normv(crossv(d1, d0));
+        float dd = -dotv(n, v0);
+        TriIsect& r = recs[i];
+        r.n[0] = n.x; r.n[1] = n.y; r.n[2] = n.z; r.d = dd;
+        int i1, i2;
+        float ax = std::fabs(n.x), ay = std::fabs(n.y), az = std::fabs(n.z);
+        if (ax > ay && ax > az) { i1 = 1; i2 = 2; }
+        else if (ay > az) { i1 = 0; i2 = 2; }
+        else { i1 = 0; i2 = 1; }
+        r.v0a = comp(v0, i1); r.v0b = comp(v0, i2);
+        r.q1x = comp(v1, i1) - comp(v0, i1); r.q1y = comp(v1, i2) - comp(v0, i2);
+        r.q2x = comp(v2, i1) - comp(v0, i1); r.q2y = comp(v2, i2) - comp(v0, i2);
+        r.axes = (uint32_t)i1 | ((uint32_t)i2 << 2);
+        r.tri = i;
+        if (n.x == n.x && n.y == n.y && n.z == n.z) { // a NaN plane can never be hit (primitives.cpp:90)
+            Prim p;
+            for (int a = 0; a < 3; a++) {
+                p.bmin[a] = std::min(comp(v0, a), std::min(comp(v1, a), comp(v2, a)));
+                p.bmax[a] = std::max(comp(v0, a), std::max(comp(v1, a), comp(v2, a)));
+                p.c[a] = 0.5f * (p.bmin[a] + p.bmax[a]);
+            }
+            p.tri = i;
+            prims.push_back(p);
+        }
+    }
+    // ---- accelerator
+    std::vector<BvhNode> nodes;
+    std::vector<TriIsect> leaf_recs;
+    uint32_t max_depth = 0;
+    {
+        if (prims.empty()) return fail(RGK_ERR_INVALID, "every triangle is degenerate");
+        BvhBuilder bb(prims, eps);
+        Box rootbox;
+        bb.nodes.reserve(prims.size());
+        bb.nodes.emplace_back(); // node 0 = root, filled below if the whole scene is one leaf
+        int code;
+        if (prims.size() <= (size_t)BvhBuilder::MAX_LEAF) {
+            code = bb.build(0, prims.size(), 1, rootbox);
+            BvhNode& r = bb.nodes[0];
+            for (int a = 0; a < 3; a++) {
+                r.lmin[a] = rootbox.mn[a]; r.lmax[a] = rootbox.mx[a];
+                r.rmin[a] = std::numeric_limits<float>::infinity(); r.rmax[a] = -std::numeric_limits<float>::infinity();
+            }
+            r.left = code; r.right = code; r.pad[0] = r.pad[1] = 0;
+        } else {
+            bb.nodes.pop_back();
+            code = bb.build(0, prims.size(), 0, rootbox);
+            if (code != 0) return fail(RGK_ERR_DEVICE, "internal: BVH root is not node 0");
+        }
+        nodes.swap(bb.nodes);
+        max_depth = bb.max_depth;
+        leaf_recs.reserve(bb.order.size());
+        for (uint32_t t : bb.order) leaf_recs.push_back(recs[t]);
+        if (bb.order.size() >= (1u << 27)) return fail(RGK_ERR_UNSUPPORTED, "too many triangles for the leaf encoding");
+    }
+    if (max_depth + 1 > 64) return fail(RGK_ERR_UNSUPPORTED, "BVH depth %u exceeds the 64-entry LDS stack", max_depth);
+    s->stack = (max_depth + 1 <= 32) ? 32 : 64;
+
+    // ---- shading arrays
+    std::vector<TriShade> tsh(nt);
+    for (uint32_t i = 0; i < nt; i++) tsh[i] = TriShade{d->tri_indices[3 * i], d->tri_indices[3 * i + 1], d->tri_indices[3 * i + 2], d->tri_material[i]};
+    std::vector<VtxAttr> vtx(nv);
+    for (uint32_t i = 0; i < nv; i++) {
+        VtxAttr& v = vtx[i];
+        v.nx = d->normals[3 * i]; v.ny = d->normals[3 * i + 1]; v.nz = d->normals[3 * i + 2];
+        v.tx = d->tangents[3 * i]; v.ty = d->tangents[3 * i + 1]; v.tz = d->tangents[3 * i + 2];
+        v.u = d->texcoords ? d->texcoords[2 * i] : 0.f;
+        v.v = d->texcoords ? d->texcoords[2 * i + 1] : 0.f;
+    }
+    std::vector<DevMaterial> mats(d->n_materials);
+    for (uint32_t i = 0; i < d->n_materials; i++) {
+        const rgk_material& m = d->materials[i];
+        DevMaterial& o = mats[i];
+        std::memset(&o, 0, sizeof(o));
+        o.kind = m.kind; o.flags = m.flags;
+        for (int k = 0; k < 3; k++) o.emission[k] = m.emission[k];
+        o.roughness = m.roughness; o.ior = m.ior; o.amount = m.amount;
+        o.tex_diffuse = m.tex_diffuse; o.tex_color = m.tex_color; o.tex_bump = m.tex_bump;
+        o.mix_m1 = m.mix_m1; o.mix_m2 = m.mix_m2;
+    }
+    std::vector<DevTexture> texs(d->n_textures);
+    std::vector<float> pool;
+    for (uint32_t i = 0; i < d->n_textures; i++) {
+        const rgk_texture& t = d->textures[i];
+        DevTexture& o = texs[i];
+        std::memset(&o, 0, sizeof(o));
+        o.kind = t.kind; o.width = t.width; o.height = t.height;
+        for (int k = 0; k < 3; k++) o.color[k] = t.color[k];
+        if (t.kind == RGK_TEX_RGB32F) {
+            if (pool.size() + (size_t)3 * t.width * t.height >= (1ull << 32)) return fail(RGK_ERR_UNSUPPORTED, "texel pool exceeds 2^32 floats");
+            o.offset = (uint32_t)pool.size();
+            pool.insert(pool.end(), t.texels, t.texels + (size_t)3 * t.width * t.height);
+        }
+    }
+    // ---- lights (scene.cpp:323-344)
+    std::vector<DevPointLight> pls(d->n_pointlights);
+    float total_point = 0.f;
+    const float PI_F = 3.14159265358979323846264338327950288f;
+    for (uint32_t i = 0; i < d->n_pointlights; i++) {
+        const rgk_pointlight& l = d->pointlights[i];
+        DevPointLight& o = pls[i];
+        for (int k = 0; k < 3; k++) { o.pos[k] = l.pos[k]; o.color[k] = l.color[k]; }
+        o.intensity = l.intensity; o.size = l.size;
+        total_point += l.intensity * 4.0f * PI_F;
+    }
+    std::vector<DevArealLight> als;
+    std::vector<DevArealTri> ats;
+    float total_areal = 0.f;
+    for (uint32_t i = 0; i < d->n_areal_lights; i++) {
+        uint32_t b = d->areal_offsets[i], e = d->areal_offsets[i + 1];
+        if (e <= b) continue;
+        std::vector<std::pair<float, uint32_t>> twa;
+        float total_area = 0.f;
+        for (uint32_t j = b; j < e; j++) {
+            uint32_t t = d->areal_tris[j];
+            V3 A = vert(d->tri_indices[3 * t]), B = vert(d->tri_indices[3 * t + 1]), C = vert(d->tri_indices[3 * t + 2]);
+            V3 c = crossv(sub(A, B), sub(C, B)); // Triangle::GetArea primitives.cpp:38-45
+            float area = 0.5f * std::sqrt(dotv(c, c));
+            twa.push_back({area, t});
+            total_area += area;
+        }
+        const rgk_material& m0 = d->materials[d->tri_material[twa[0].second]];
+        std::sort(twa.rbegin(), twa.rend()); // descending by (area, index)
+        DevArealLight al{};
+        al.total_area = total_area;
+        for (int k = 0; k < 3; k++) al.emission[k] = m0.emission[k];
+        al.power = total_area * (m0.emission[0] + m0.emission[1] + m0.emission[2]);
+        al.first = (uint32_t)ats.size();
+        al.count = (uint32_t)twa.size();
+        for (auto& p : twa) {
+            DevArealTri at{};
+            at.area = p.first; at.tri = p.second;
+            uint32_t ia = d->tri_indices[3 * p.second], ib = d->tri_indices[3 * p.second + 1], ic = d->tri_indices[3 * p.second + 2];
+            for (int k = 0; k < 3; k++) {
+                at.a[k] = d->vertices[3 * ia + k]; at.b[k] = d->vertices[3 * ib + k]; at.c[k] = d->vertices[3 * ic + k];
+                at.normal_a[k] = d->normals[3 * ia + k];
+            }
+            ats.push_back(at);
+        }
+        total_areal += al.power;
+        als.push_back(al);
+    }
+    std::vector<DevHaltonDim> hd;
+    std::vector<uint16_t> hp;
+    build_halton(hd, hp);
+
+    // ---- upload
+    if ((rc = s->nodes.upload(nodes)) || (rc = s->tris.upload(leaf_recs)) || (rc = s->tri_shade.upload(tsh)) ||
+        (rc = s->vtx.upload(vtx)) || (rc = s->materials.upload(mats)) || (rc = s->textures.upload(texs)) ||
+        (rc = s->texels.upload(pool)) || (rc = s->pointlights.upload(pls)) || (rc = s->areal.upload(als)) ||
+        (rc = s->areal_tris.upload(ats)) || (rc = s->hdims.upload(hd)) || (rc = s->hperm.upload(hp)))
+        return rc;
+    if (d->ltc_ggx) { std::vector<float> t(d->ltc_ggx, d->ltc_ggx + 5 * 4096); if ((rc = s->ltc_ggx.upload(t))) return rc; }
+    if (d->ltc_beckmann) { std::vector<float> t(d->ltc_beckmann, d->ltc_beckmann + 5 * 4096); if ((rc = s->ltc_beckmann.upload(t))) return rc; }
+    ds.nodes = s->nodes.p; ds.tris = s->tris.p; ds.tri_shade = s->tri_shade.p; ds.vtx = s->vtx.p;
+    ds.materials = s->materials.p; ds.textures = s->textures.p; ds.texels = s->texels.p;
+    ds.pointlights = s->pointlights.p; ds.areal = s->areal.p; ds.areal_tris = s->areal_tris.p;
+    ds.ltc_ggx = s->ltc_ggx.p; ds.ltc_beckmann = s->ltc_beckmann.p; ds.hdims = s->hdims.p; ds.hperm = s->hperm.p;
+    ds.n_pointlights = (uint32_t)pls.size(); ds.n_areal = (uint32_t)als.size();
+    ds.total_point_power = total_point; ds.total_areal_power = total_areal;
+    ds.has_texcoords = d->texcoords ? 1u : 0u;
+    ds.sky_mode = d->sky_mode;
+    for (int k = 0; k < 3; k++) ds.sky_color[k] = d->sky_color[k];
+    ds.sky_intensity = d->sky_intensity; ds.sky_rotate = d->sky_rotate; ds.sky_texture = d->sky_texture;
+
+    rgk_scene_info& inf = s->info;
+    inf.epsilon = eps;
+    for (int a = 0; a < 3; a++) { inf.bbox_min[a] = ds.bb_min[a]; inf.bbox_max[a] = ds.bb_max[a]; }
+    inf.total_areal_power = total_areal; inf.total_point_power = total_point;
+    inf.n_nodes = (uint32_t)nodes.size(); inf.node_bytes = RGK_NODE_BYTES; inf.tri_bytes = RGK_TRI_BYTES;
+    inf.max_depth = max_depth; inf.n_leaf_refs = (uint32_t)leaf_recs.size();
+    guard.s = nullptr;
+    *out = s;
+    return RGK_OK;
+}
+
+void rgk_scene_destroy(rgk_scene* s) { delete s; }
+
+int rgk_scene_get_info(const rgk_scene* s, rgk_scene_info* out) {
+    if (!s || !out) return fail(RGK_ERR_INVALID, "null argument");
+    *out = s->info;
+    return RGK_OK;
+}
+
+int rgk_generate_task_list(uint32_t tile_size, uint32_t xres, uint32_t yres, float mid_x, float mid_y, uint32_t seedstart,
+                           uint32_t seedcount_base, rgk_tile* tiles, uint32_t* n_tiles) {
+    if (!n_tiles || tile_size == 0) return fail(RGK_ERR_INVALID, "bad argument");
+    struct T { rgk_tile t; float d; };
+    std::vector<T> v;
+    for (uint32_t yp = 0; yp < yres; yp += tile_size)
+        for (uint32_t xp = 0; xp < xres; xp += tile_size) {
+            T t;
+            t.t.x0 = xp; t.t.x1 = std::min(xres, xp + tile_size);
+            t.t.y0 = yp; t.t.y1 = std::min(yres, yp + tile_size);
+            t.t.seed = 0;
+            float mx = (t.t.x0 + t.t.x1) / 2.0f, my = (t.t.y0 + t.t.y1) / 2.0f; // RenderTask::midpoint tracer.hpp:18
+            float dx = mid_x - mx, dy = mid_y - my;
+            t.d = std::sqrt(dx * dx + dy * dy);
+            v.push_back(t);
+        }
+    std::stable_sort(v.begin(), v.end(), [](const T& a, const T& b) { return a.d < b.d; });
+    if (tiles) {
+        if (*n_tiles < v.size()) return fail(RGK_ERR_INVALID, "tile buffer too small (%u < %zu)", *n_tiles, v.size());
+        for (size_t i = 0; i < v.size(); i++) { tiles[i] = v[i].t; tiles[i].seed = seedstart + seedcount_base + (uint32_t)i; }
+    }
+    *n_tiles = (uint32_t)v.size();
+    return RGK_OK;
+}
+
+static void make_camera(const rgk_camera* c, DevCamera& o) {
+    // Camera::Camera, reference src/camera.cpp:7-24
+    V3 origin{c->pos[0], c->pos[1], c->pos[2]}, lookat{c->lookat[0], c->lookat[1], c->lookat[2]}, up{c->up[0], c->up[1], c->up[2]};
+    V3 direction = normv(sub(lookat, origin));
+    V3 left = normv(crossv(up, direction));
+    up = normv(crossv(left, direction));
+    V3 vx = scale(scale(left, -c->xview), c->focus_plane);
+    V3 vy = scale(scale(up, c->yview), c->focus_plane);
+    V3 a = {origin.x + direction.x * c->focus_plane, origin.y + direction.y * c->focus_plane, origin.z + direction.z * c->focus_plane};
+    V3 hy = scale(vy, 0.5f), hx = scale(vx, 0.5f);
+    V3 vs = sub(sub(a, hy), hx);
+    auto put = [](float* dst, V3 v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; };
+    put(o.origin, origin); put(o.direction, direction); put(o.up, up); put(o.left, left);
+    put(o.viewscreen, vs); put(o.viewscreen_x, vx); put(o.viewscreen_y, vy);
+    o.lens_size = c->lens_size; o.xsize = c->xsize; o.ysize = c->ysize;
+}
+
+static size_t batch_paths() {
+    const char* e = getenv("RGK_BATCH_PATHS");
+    size_t b = e ? strtoull(e, nullptr, 10) : (size_t)1 << 25;
+    if (b < 1024) b = 1024;
+    return b;
+}
+
+int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_params* prm, const rgk_tile* tiles, uint32_t n_tiles,
+                            float* d_accum_rgb, uint32_t* d_accum_count, rgk_counters* counters) {
+    if (!s || !camera || !prm || (!tiles && n_tiles) || !d_accum_rgb || !d_accum_count) return fail(RGK_ERR_INVALID, "null argument");
+    if (prm->xres == 0 || prm->yres == 0 || prm->xres > 65535 || prm->yres > 65535) return fail(RGK_ERR_INVALID, "resolution out of range");
+    if (prm->multisample == 0) return fail(RGK_ERR_INVALID, "multisample must be >= 1");
+    if (prm->depth > RGK_MAX_DEPTH) return fail(RGK_ERR_UNSUPPORTED, "recursion depth %u > %d", prm->depth, RGK_MAX_DEPTH);
+    if (prm->reverse != 0) return fail(RGK_ERR_UNSUPPORTED, "reverse (light sub-paths) is not implemented on the HIP path yet");
+    if (prm->sampler != RGK_SAMPLER_HALTON) return fail(RGK_ERR_UNSUPPORTED, "the HIP path implements the Halton sampler only");
+    HIPCHK(hipSetDevice(s->device));
+    if (counters) std::memset(counters, 0, sizeof(*counters));
+    // ---- pixel list in Tracer::Render order, per-pixel seeds (a1, a2)
+    std::vector<uint32_t> pxy, pseed;
+    for (uint32_t i = 0; i < n_tiles; i++) {
+        const rgk_tile& t = tiles[i];
+        if (t.x1 > prm->xres || t.y1 > prm->yres || t.x0 > t.x1 || t.y0 > t.y1) return fail(RGK_ERR_INVALID, "tile %u outside the frame", i);
+        uint32_t seed = t.seed;
+        for (uint32_t y = t.y0; y < t.y1; y++)
+            for (uint32_t x = t.x0; x < t.x1; x++) {
+                seed += 0x42424242u; // path_tracer.cpp:47
+                pxy.push_back(x | (y << 16));
+                pseed.push_back(seed);
+            }
+    }
+    const size_t P = pxy.size();
+    if (P == 0) return RGK_OK;
+    int rc;
+    if ((rc = s->pix_xy.upload(pxy)) || (rc = s->pix_seed.upload(pseed))) return rc;
+    const size_t B = batch_paths();
+    const size_t npix_pass = std::min(P, B);
+    const uint32_t ns_pass = (uint32_t)std::max<size_t>(1, std::min<size_t>(prm->multisample, B / npix_pass));
+    if ((rc = ensure_workspace(s, npix_pass * ns_pass))) return rc;
+    if ((rc = s->pixsum.alloc(P))) return rc;
+
+    DevCamera cam;
+    make_camera(camera, cam);
+    hipStream_t st = s->stream;
+    const bool count_stats = (prm->flags & RGK_FLAG_COUNT_TRAVERSAL) != 0;
+    const bool timing = (prm->flags & RGK_FLAG_TIME_KERNELS) != 0;
+    HIPCHK(hipMemsetAsync(s->stats.p, 0, 8 * sizeof(unsigned long long), st));
+    struct Ev { int cls; hipEvent_t a, b; };
+    std::vector<Ev> evs;
+    size_t ev_used = 0;
+    auto ev_get = [&](hipEvent_t& e) -> int {
+        if (ev_used == s->events.size()) { hipEvent_t n; HIPCHK(hipEventCreate(&n)); s->events.push_back(n); }
+        e = s->events[ev_used++];
+        return 0;
+    };
+#define TIMED(cls_, call)                                                \
+    do {                                                                 \
+        if (timing) {                                                    \
+            Ev ev; ev.cls = cls_;                                        \
+            if ((rc = ev_get(ev.a)) || (rc = ev_get(ev.b))) return rc;   \
+            HIPCHK(hipEventRecord(ev.a, st));                            \
+            call;                                                        \
+            HIPCHK(hipEventRecord(ev.b, st));                            \
+            evs.push_back(ev);                                           \
+        } else { call; }                                                 \
+    } while (0)
+
+    uint64_t path_rays = 0, shadow_rays = 0;
+    PassParams pp{};
+    pp.multisample = prm->multisample; pp.depth = prm->depth; pp.xres = prm->xres; pp.yres = prm->yres;
+    pp.clamp = prm->clamp; pp.russian = prm->russian; pp.bumpmap_scale = prm->bumpmap_scale; pp.reverse = prm->reverse;
+    pp.pix_xy = s->pix_xy.p; pp.pix_seed = s->pix_seed.p;
+    for (size_t j0 = 0; j0 < P; j0 += npix_pass) {
+        pp.j0 = (uint32_t)j0;
+        pp.npix = (uint32_t)std::min(npix_pass, P - j0);
+        for (uint32_t s0 = 0; s0 < prm->multisample; s0 += ns_pass) {
+            pp.s0 = s0;
+            pp.ns = std::min(ns_pass, prm->multisample - s0);
+            const uint32_t n0 = pp.npix * pp.ns;
+            TIMED(3, rgk_launch_init_counters(st, s->counters.p, n0));
+            TIMED(3, rgk_launch_raygen(st, s->dev, cam, pp, s->rayA[0].p, s->rayB[0].p, s->thr.p, s->tot.p));
+            for (uint32_t b = 0; b < prm->depth; b++) {
+                int q = b & 1;
+                TIMED(0, rgk_launch_trace_closest(st, s->dev, s->stack, count_stats, s->rayA[q].p, s->rayB[q].p, nullptr, s->hit.p,
+                                                  s->counters.p + RGK_CNT_QUEUE + b, s->counters.p + RGK_CNT_FETCH_T + b, s->stats.p));
+                TIMED(2, rgk_launch_shade(st, s->dev, cam, pp, b, s->rayA[q].p, s->rayB[q].p, s->hit.p, s->thr.p, s->tot.p,
+                                          s->rayA[q ^ 1].p, s->rayB[q ^ 1].p, s->shA.p, s->shB.p, s->shC.p, s->counters.p));
+                TIMED(1, rgk_launch_trace_shadow(st, s->dev, s->stack, count_stats, s->shA.p, s->shB.p, s->shC.p, s->tot.p, nullptr,
+                                                 s->counters.p + RGK_CNT_SHADOW + b, s->counters.p + RGK_CNT_FETCH_S + b, s->stats.p));
+            }
+            TIMED(3, rgk_launch_resolve(st, pp, s->tot.p, s->pixsum.p, d_accum_rgb, d_accum_count));
+            HIPCHK(hipMemcpyAsync(s->h_counters, s->counters.p, RGK_CNT_TOTAL * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            for (uint32_t b = 0; b < prm->depth; b++) { path_rays += s->h_counters[RGK_CNT_QUEUE + b]; shadow_rays += s->h_counters[RGK_CNT_SHADOW + b]; }
+        }
+    }
+    HIPCHK(hipGetLastError());
+    if (counters) {
+        counters->paths = (uint64_t)P * prm->multisample;
+        counters->path_rays = path_rays;
+        counters->shadow_rays = shadow_rays;
+        if (count_stats) {
+            unsigned long long h[8];
+            HIPCHK(hipMemcpy(h, s->stats.p, sizeof(h), hipMemcpyDeviceToHost));
+            counters->node_visits = h[0]; counters->tri_tests = h[1]; counters->shadow_node_visits = h[2]; counters->shadow_tri_tests = h[3];
+        }
+        for (auto& e : evs) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
+            if (e.cls == 0) { counters->ms_trace += ms; counters->n_trace_launches++; }
+            else if (e.cls == 1) { counters->ms_shadow += ms; counters->n_shadow_launches++; }
+            else if (e.cls == 2) { counters->ms_shade += ms; counters->n_shade_launches++; }
+            else counters->ms_other += ms;
+        }
+    }
+    return RGK_OK;
+#undef TIMED
+}
+
+int rgk_render_round(rgk_scene* s, const rgk_camera* camera, const rgk_params* prm, const rgk_tile* tiles, uint32_t n_tiles,
+                     float* accum_rgb, uint32_t* accum_count, rgk_counters* counters) {
+    if (!s || !prm || !accum_rgb || !accum_count) return fail(RGK_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(s->device));
+    const size_t P = (size_t)prm->xres * prm->yres;
+    float* d_rgb = nullptr;
+    uint32_t* d_cnt = nullptr;
+    HIPCHK(hipMalloc((void**)&d_rgb, P * 3 * sizeof(float)));
+    hipError_t e = hipMalloc((void**)&d_cnt, P * sizeof(uint32_t));
+    if (e != hipSuccess) { (void)hipFree(d_rgb); return fail(RGK_ERR_OOM, "hipMalloc: %s", hipGetErrorString(e)); }
+    int rc = RGK_OK;
+    auto chk = [&](hipError_t x, const char* what) { if (x != hipSuccess && rc == RGK_OK) rc = fail(RGK_ERR_DEVICE, "%s: %s", what, hipGetErrorString(x)); };
+    chk(hipMemcpy(d_rgb, accum_rgb, P * 3 * sizeof(float), hipMemcpyHostToDevice), "upload accumulator");
+    chk(hipMemcpy(d_cnt, accum_count, P * sizeof(uint32_t), hipMemcpyHostToDevice), "upload counts");
+    if (rc == RGK_OK) rc = rgk_render_round_device(s, camera, prm, tiles, n_tiles, d_rgb, d_cnt, counters);
+    if (rc == RGK_OK) {
+        chk(hipMemcpy(accum_rgb, d_rgb, P * 3 * sizeof(float), hipMemcpyDeviceToHost), "download accumulator");
+        chk(hipMemcpy(accum_count, d_cnt, P * sizeof(uint32_t), hipMemcpyDeviceToHost), "download counts");
+    }
+    (void)hipFree(d_rgb);
+    (void)hipFree(d_cnt);
+    return rc;
+}
+
+int rgk_trace_closest(rgk_scene* s, uint32_t n, const float* rays, const int32_t* ignore, rgk_hit* hits, rgk_counters* counters) {
+    if (!s || (!rays && n) || (!hits && n)) return fail(RGK_ERR_INVALID, "null argument");
+    if (counters) std::memset(counters, 0, sizeof(*counters));
+    if (n == 0) return RGK_OK;
+    HIPCHK(hipSetDevice(s->device));
+    int rc;
+    if ((rc = ensure_workspace(s, n)) || (rc = s->nearfar.alloc(n)) || (rc = s->scratch_f.alloc((size_t)8 * n)) || (rc = s->scratch_u.alloc((size_t)5 * n)))
+        return rc;
+    hipStream_t st = s->stream;
+    HIPCHK(hipMemcpyAsync(s->scratch_f.p, rays, (size_t)8 * n * sizeof(float), hipMemcpyHostToDevice, st));
+    int32_t* d_ign = nullptr;
+    if (ignore) {
+        d_ign = (int32_t*)s->scratch_u.p;
+        HIPCHK(hipMemcpyAsync(d_ign, ignore, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    }
+    HIPCHK(hipMemsetAsync(s->stats.p, 0, 8 * sizeof(unsigned long long), st));
+    rgk_launch_init_counters(st, s->counters.p, n);
+    rgk_launch_pack_rays(st, n, s->scratch_f.p, d_ign, s->rayA[0].p, s->rayB[0].p, s->nearfar.p);
+    rgk_launch_trace_closest(st, s->dev, s->stack, counters != nullptr, s->rayA[0].p, s->rayB[0].p, s->nearfar.p, s->hit.p,
+                             s->counters.p + RGK_CNT_QUEUE, s->counters.p + RGK_CNT_FETCH_T, s->stats.p);
+    rgk_hit* d_hits = (rgk_hit*)s->scratch_u.p; // 5 dwords per hit; reuses the ignore buffer after the trace
+    rgk_launch_unpack_hits(st, n, s->hit.p, d_hits);
+    HIPCHK(hipMemcpyAsync(hits, d_hits, (size_t)n * sizeof(rgk_hit), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    if (counters) {
+        unsigned long long h[8];
+        HIPCHK(hipMemcpy(h, s->stats.p, sizeof(h), hipMemcpyDeviceToHost));
+        counters->node_visits = h[0]; counters->tri_tests = h[1]; counters->path_rays = n;
+    }
+    return RGK_OK;
+}
+
+int rgk_trace_visibility(rgk_scene* s, uint32_t n, const float* a, const float* b, uint8_t* visible, rgk_counters* counters) {
+    if (!s || (n && (!a || !b || !visible))) return fail(RGK_ERR_INVALID, "null argument");
+    if (counters) std::memset(counters, 0, sizeof(*counters));
+    if (n == 0) return RGK_OK;
+    HIPCHK(hipSetDevice(s->device));
+    int rc;
+    if ((rc = ensure_workspace(s, n)) || (rc = s->scratch_f.alloc((size_t)6 * n)) || (rc = s->scratch_u.alloc(n))) return rc;
+    hipStream_t st = s->stream;
+    HIPCHK(hipMemcpyAsync(s->scratch_f.p, a, (size_t)3 * n * sizeof(float), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(s->scratch_f.p + (size_t)3 * n, b, (size_t)3 * n * sizeof(float), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(s->stats.p, 0, 8 * sizeof(unsigned long long), st));
+    rgk_launch_init_counters(st, s->counters.p, n);
+    rgk_launch_pack_visibility(st, s->dev, n, s->scratch_f.p, s->scratch_f.p + (size_t)3 * n, s->shA.p, s->shB.p, s->shC.p);
+    rgk_launch_trace_shadow(st, s->dev, s->stack, counters != nullptr, s->shA.p, s->shB.p, s->shC.p, s->tot.p, (uint8_t*)s->scratch_u.p,
+                            s->counters.p + RGK_CNT_QUEUE, s->counters.p + RGK_CNT_FETCH_S, s->stats.p);
+    HIPCHK(hipMemcpyAsync(visible, s->scratch_u.p, n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    if (counters) {
+        unsigned long long h[8];
+        HIPCHK(hipMemcpy(h, s->stats.p, sizeof(h), hipMemcpyDeviceToHost));
+        counters->shadow_node_visits = h[2]; counters->shadow_tri_tests = h[3]; counters->shadow_rays = n;
+    }
+    return RGK_OK;
+}
+
+int rgk_sampler_eval(uint32_t n, const uint32_t* seed, const uint32_t* index, const uint32_t* dim, int is2d, float* out) {
+    if (n && (!seed || !index || !dim || !out)) return fail(RGK_ERR_INVALID, "null argument");
+    if (n == 0) return RGK_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(RGK_ERR_NO_DEVICE, "no HIP device visible");
+    std::vector<DevHaltonDim> hd;
+    std::vector<uint16_t> hp;
+    build_halton(hd, hp);
+    DevBuf<DevHaltonDim> dh;
+    DevBuf<uint16_t> dp;
+    DevBuf<uint32_t> ds_, di, dd;
+    DevBuf<float> dout;
+    int rc = RGK_OK;
+    std::vector<uint32_t> vs(seed, seed + n), vi(index, index + n), vd(dim, dim + n);
+    if (!(rc = dh.upload(hd)) && !(rc = dp.upload(hp)) && !(rc = ds_.upload(vs)) && !(rc = di.upload(vi)) && !(rc = dd.upload(vd)) &&
+        !(rc = dout.alloc((size_t)2 * n))) {
+        DevScene sc{};
+        sc.hdims = dh.p; sc.hperm = dp.p;
+        rgk_launch_sampler_eval(nullptr, sc, n, ds_.p, di.p, dd.p, is2d, dout.p);
+        hipError_t e = hipMemcpy(out, dout.p, (size_t)2 * n * sizeof(float), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(RGK_ERR_DEVICE, "sampler eval: %s", hipGetErrorString(e));
+    }
+    dh.release(); dp.release(); ds_.release(); di.release(); dd.release(); dout.release();
+    return rc;
+}
+
+} // extern "C"

@@ -1,0 +1,45 @@
+// Launch interface between the host runtime (rgk_host.cpp) and the kernels (rgk_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "device_types.h"
+
+#define RGK_TRACE_BLOCK 256
+#define RGK_SHADE_BLOCK 256
+#define RGK_MAX_DEPTH 62
+
+// device counter block (uint32), zeroed per pass by k_init_counters
+#define RGK_CNT_QUEUE 0     // [b]  rays in bounce b's queue        (b = 0..depth)
+#define RGK_CNT_SHADOW 64   // [b]  shadow rays issued at bounce b
+#define RGK_CNT_FETCH_T 128 // [b]  work-fetch cursor of k_trace_closest at bounce b
+#define RGK_CNT_FETCH_S 192 // [b]  work-fetch cursor of k_trace_shadow at bounce b
+#define RGK_CNT_TOTAL 256
+
+// One pass = pixels [j0, j0+npix) of the round's pixel list x samples [s0, s0+ns).
+// Path slot = (s - s0) * npix + (j - j0).
+struct PassParams {
+    uint32_t j0, npix, s0, ns;
+    uint32_t multisample, depth, xres, yres;
+    float clamp, russian, bumpmap_scale;
+    uint32_t reverse;
+    const uint32_t* pix_xy;   // x | y << 16, per pixel of the round
+    const uint32_t* pix_seed; // PathTracer::samplerSeed for that pixel (a2)
+};
+
+void rgk_launch_init_counters(hipStream_t st, uint32_t* counters, uint32_t n0);
+void rgk_launch_raygen(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, float4* rayA, float4* rayB,
+                       float4* thr, float4* tot);
+void rgk_launch_trace_closest(hipStream_t st, const DevScene& sc, int stack, bool count_stats, const float4* rayA, const float4* rayB,
+                              const float2* nearfar, float4* hit, const uint32_t* count_ptr, uint32_t* fetch, unsigned long long* stats);
+void rgk_launch_trace_shadow(hipStream_t st, const DevScene& sc, int stack, bool count_stats, const float4* shA, const float4* shB,
+                             const float4* shC, float4* tot, uint8_t* vis_out, const uint32_t* count_ptr, uint32_t* fetch,
+                             unsigned long long* stats);
+void rgk_launch_shade(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t bounce, const float4* rayA,
+                      const float4* rayB, const float4* hit, float4* thr, float4* tot, float4* nextA, float4* nextB, float4* shA,
+                      float4* shB, float4* shC, uint32_t* counters);
+void rgk_launch_resolve(hipStream_t st, const PassParams& pp, const float4* tot, float4* pixsum, float* accum_rgb, uint32_t* accum_count);
+void rgk_launch_pack_rays(hipStream_t st, uint32_t n, const float* rays, const int32_t* ignore, float4* rayA, float4* rayB, float2* nearfar);
+void rgk_launch_pack_visibility(hipStream_t st, const DevScene& sc, uint32_t n, const float* a, const float* b, float4* shA, float4* shB,
+                                float4* shC);
+void rgk_launch_unpack_hits(hipStream_t st, uint32_t n, const float4* hit, rgk_hit* out);
+void rgk_launch_sampler_eval(hipStream_t st, const DevScene& sc, uint32_t n, const uint32_t* seed, const uint32_t* index,
+                             const uint32_t* dim, int is2d, float* out);

@@ -1,0 +1,555 @@
+// Hand-written HIP kernels for gfx950 (MI355X): the wavefront path-tracing pipeline.
+//
+//   k_raygen        K1  RenderPixel ray generation      reference src/path_tracer.cpp:53-61, src/camera.cpp:32-46
+//   k_trace_closest K2  FindIntersectKdOtherThan         reference src/scene_intersect.cpp:211-327 + src/primitives.cpp:75-166
+//   k_shade         K3/K4/K6/K7  GeneratePath body + NEE + compaction  reference src/path_tracer.cpp:134-300,427-460,485-496
+//   k_trace_shadow  K5  Scene::Visibility + accumulate   reference src/scene.cpp:670-673, src/path_tracer.cpp:431,455-457
+//   k_resolve       K9  clamp / NaN scrub / AddPixel     reference src/path_tracer.cpp:502-507, src/tracer.cpp:18, src/texture.cpp:342-347
+//
+// Design: one path per slot, SoA-of-float4 queues so every lane moves 16 B
+// per load; persistent waves pull 64 rays at a time from a device-side counter; a
+// per-lane traversal stack lives in LDS ([depth][lane] -> conflict-free); surviving
+// paths are compacted into the next bounce's queue with a wave ballot + prefix popcount
+// and one atomic per wave.  No MFMA: there is no dense contraction on this path.
+#include <hip/hip_runtime.h>
+#include "rgk_device.h"
+#include "rgk_kernels.h"
+
+#define STACK_SENTINEL 0x7fffffff
+
+// ------------------------------------------------------------------ triangle test (a8)
+// Triangle::TestIntersection, reference src/primitives.cpp:75-166.  r0..r2 = TriIsect.
+__device__ __forceinline__ bool tri_test(const float4 r0, const float4 r1, const float4 r2, const f3 o, const f3 d,
+                                         const float eps, float& t, float& alpha, float& beta) {
+    f3 n = mk3(r0.x, r0.y, r0.z);
+    double dotv = (double)dot3(d, n);
+    if (dotv != dotv) return false;
+    if (dotv < (double)eps && dotv > (double)(-eps)) return false;
+    double dot2 = (double)dot3(o, n);
+    t = (float)(-((double)r0.w + dot2) / dotv);
+    uint32_t axes = __float_as_uint(r2.z);
+    int i1 = axes & 3, i2 = (axes >> 2) & 3;
+    float px = comp(o, i1) + comp(d, i1) * t;
+    float py = comp(o, i2) + comp(d, i2) * t;
+    float q0x = px - r1.x, q0y = py - r1.y;
+    float q1x = r1.z, q1y = r1.w, q2x = r2.x, q2y = r2.y;
+    if (q1x > -eps && q1x < eps) {
+        beta = q0x / q2x;
+        if (beta < 0 || beta > 1) return false;
+        alpha = (q0y - beta * q2y) / q1y;
+    } else {
+        beta = (q0y * q1x - q0x * q1y) / (q2y * q1x - q2x * q1y);
+        if (beta < 0 || beta > 1) return false;
+        alpha = (q0x - beta * q2x) / q1x;
+    }
+    if (alpha < 0 || (double)(alpha + beta) > 1.0) return false;
+    return true;
+}
+
+// Scene-bbox clip of [near, far], reference src/scene_intersect.cpp:223-232
+__device__ __forceinline__ bool clip_to_scene(const DevScene& sc, f3 o, f3 d, float tnear, float tfar, float& t0, float& t1) {
+    t0 = tnear; t1 = tfar;
+    for (int i = 0; i < 3; ++i) {
+        float invRayDir = 1.f / comp(d, i);
+        float tN = (sc.bb_min[i] - comp(o, i)) * invRayDir;
+        float tF = (sc.bb_max[i] - comp(o, i)) * invRayDir;
+        if (tN > tF) { float s = tN; tN = tF; tF = s; }
+        t0 = tN > t0 ? tN : t0;
+        t1 = tF < t1 ? tF : t1;
+        if (t0 > t1) return false;
+    }
+    return true;
+}
+
+// Slab test of one child box against [tlo, thi]; NaNs (0*inf) drop out of fmin/fmax, which
+// only ever widens the interval (conservative).
+__device__ __forceinline__ bool box_test(float bx0, float by0, float bz0, float bx1, float by1, float bz1, f3 o, f3 inv,
+                                         float tlo, float thi, float& tentry) {
+    float tx0 = (bx0 - o.x) * inv.x, tx1 = (bx1 - o.x) * inv.x;
+    float ty0 = (by0 - o.y) * inv.y, ty1 = (by1 - o.y) * inv.y;
+    float tz0 = (bz0 - o.z) * inv.z, tz1 = (bz1 - o.z) * inv.z;
+    float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tlo));
+    float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), thi));
+    tentry = tn;
+    return tn <= tf;
+}
+
+// One ray through the BVH.  Result semantics = the reference's kd traversal: nearest
+// accepted hit with t in [t0 - eps, t1 + eps] (t0,t1 = the ray's range clipped to the
+// padded scene box), first-tested wins exact ties, `ignore` skipped.  ANY: stop at the
+// first accepted hit (Scene::Visibility only asks whether .triangle is set).
+template <bool ANY, bool COUNT, int STACK>
+__device__ __forceinline__ void traverse(const DevScene& sc, int* __restrict__ stack /* [STACK][blockDim] + tid */, const int stride,
+                                         f3 o, f3 d, float tnear, float tfar, uint32_t ignore, float& best_t, float& best_a,
+                                         float& best_b, int& best_tri, uint32_t& n_nodes, uint32_t& n_tris) {
+    best_t = __builtin_inff();
+    best_tri = -1;
+    best_a = 0.f; best_b = 0.f;
+    float t0, t1;
+    if (!clip_to_scene(sc, o, d, tnear, tfar, t0, t1)) return;
+    const float eps = sc.epsilon;
+    const float tlo = t0 - eps, thi = t1 + eps;
+    f3 inv = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+    const float4* __restrict__ nodes = reinterpret_cast<const float4*>(sc.nodes);
+    const float4* __restrict__ tris = reinterpret_cast<const float4*>(sc.tris);
+    int sp = 0;
+    int cur = 0;
+    for (;;) {
+        while (cur >= 0 && cur != STACK_SENTINEL) {
+            const float4 n0 = nodes[4 * cur + 0], n1 = nodes[4 * cur + 1], n2 = nodes[4 * cur + 2], n3 = nodes[4 * cur + 3];
+            if (COUNT) n_nodes++;
+            float limit = ANY ? thi : fminf(thi, best_t);
+            float tl, tr;
+            bool hl = box_test(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, o, inv, tlo, limit, tl);
+            bool hr = box_test(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, o, inv, tlo, limit, tr);
+            int cl = __float_as_int(n3.x), cr = __float_as_int(n3.y);
+            if (hl && hr) {
+                bool lfirst = tl <= tr;
+                int nearc = lfirst ? cl : cr, farc = lfirst ? cr : cl;
+                if (sp < STACK) { stack[sp * stride] = farc; sp++; }
+                cur = nearc;
+            } else if (hl) cur = cl;
+            else if (hr) cur = cr;
+            else {
+                if (sp == 0) { cur = STACK_SENTINEL; break; }
+                sp--; cur = stack[sp * stride];
+            }
+        }
+        if (cur == STACK_SENTINEL) break;
+        // leaf
+        uint32_t code = ~(uint32_t)cur;
+        uint32_t first = code >> 4, cnt = (code & 15u) + 1u;
+        for (uint32_t k = 0; k < cnt; k++) {
+            const float4 r0 = tris[3 * (first + k) + 0], r1 = tris[3 * (first + k) + 1], r2 = tris[3 * (first + k) + 2];
+            uint32_t tid = __float_as_uint(r2.w);
+            if (tid == ignore) continue;
+            if (COUNT) n_tris++;
+            float t, al, be;
+            if (tri_test(r0, r1, r2, o, d, eps, t, al, be)) {
+                if (t < tlo || t > thi) continue;
+                if (t < best_t) { best_t = t; best_tri = (int)tid; best_a = al; best_b = be; if (ANY) return; }
+            }
+        }
+        if (sp == 0) break;
+        sp--; cur = stack[sp * stride];
+    }
+}
+
+// ------------------------------------------------------------------ K2: closest hit
+template <bool COUNT, int STACK>
+__global__ __launch_bounds__(RGK_TRACE_BLOCK) void k_trace_closest(const DevScene sc, const float4* __restrict__ rayA,
+                                                                    const float4* __restrict__ rayB, const float2* __restrict__ nearfar,
+                                                                    float4* __restrict__ hit, const uint32_t* __restrict__ count_ptr,
+                                                                    uint32_t* __restrict__ fetch, unsigned long long* __restrict__ stats) {
+    __shared__ int lds_stack[STACK * RGK_TRACE_BLOCK];
+    int* stack = lds_stack + threadIdx.x;
+    const uint32_t count = *count_ptr;
+    const int lane = threadIdx.x & 63;
+    uint32_t n_nodes = 0, n_tris = 0;
+    for (;;) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(fetch, 64u);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= count) break;
+        uint32_t i = base + lane;
+        if (i < count) {
+            const float4 a = rayA[i], b = rayB[i];
+            f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
+            float tn = 0.0f, tf = 10000.0f; // Ray::near / Ray::far defaults, reference src/ray.hpp:25-26
+            if (nearfar) { float2 nf = nearfar[i]; tn = nf.x; tf = nf.y; }
+            float bt, ba, bb; int btri;
+            traverse<false, COUNT, STACK>(sc, stack, RGK_TRACE_BLOCK, o, d, tn, tf, __float_as_uint(b.z), bt, ba, bb, btri, n_nodes, n_tris);
+            hit[i] = make_float4(bt, ba, bb, __int_as_float(btri));
+        }
+    }
+    if (COUNT) {
+        atomicAdd(&stats[0], (unsigned long long)n_nodes);
+        atomicAdd(&stats[1], (unsigned long long)n_tris);
+    }
+}
+
+// ------------------------------------------------------------------ K5: shadow rays + accumulate
+// shA = (o.xyz, d.x)  shB = (d.y, d.z, far, slot)  shC = (radiance.rgb, near)
+template <bool COUNT, int STACK>
+__global__ __launch_bounds__(RGK_TRACE_BLOCK) void k_trace_shadow(const DevScene sc, const float4* __restrict__ shA,
+                                                                   const float4* __restrict__ shB, const float4* __restrict__ shC,
+                                                                   float4* __restrict__ tot, uint8_t* __restrict__ vis_out,
+                                                                   const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ fetch,
+                                                                   unsigned long long* __restrict__ stats) {
+    __shared__ int lds_stack[STACK * RGK_TRACE_BLOCK];
+    int* stack = lds_stack + threadIdx.x;
+    const uint32_t count = *count_ptr;
+    const int lane = threadIdx.x & 63;
+    uint32_t n_nodes = 0, n_tris = 0;
+    for (;;) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(fetch, 64u);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= count) break;
+        uint32_t i = base + lane;
+        if (i < count) {
+            const float4 a = shA[i], b = shB[i], c = shC[i];
+            f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
+            float bt, ba, bb; int btri;
+            traverse<true, COUNT, STACK>(sc, stack, RGK_TRACE_BLOCK, o, d, c.w, b.z, 0xffffffffu, bt, ba, bb, btri, n_nodes, n_tris);
+            if (vis_out) vis_out[i] = btri < 0;
+            else if (btri < 0) {
+                uint32_t slot = __float_as_uint(b.w);
+                float4 t = tot[slot]; // one path per slot, one shadow ray per path and bounce: no race
+                t.x = t.x + c.x; t.y = t.y + c.y; t.z = t.z + c.z;
+                tot[slot] = t;
+            }
+        }
+    }
+    if (COUNT) {
+        atomicAdd(&stats[2], (unsigned long long)n_nodes);
+        atomicAdd(&stats[3], (unsigned long long)n_tris);
+    }
+}
+
+// ------------------------------------------------------------------ K1: ray generation
+// Camera::GetPixelRay / GetPixelRayLens, reference src/camera.cpp:26-46; Ray ctor src/ray.hpp:10-13
+__device__ __forceinline__ void camera_ray(const DevCamera& cam, int x, int y, int xres, int yres, float2 off, float2 lens, f3& o, f3& d) {
+    float fx = (x + off.x) / (float)(xres), fy = (y + off.y) / (float)(yres);
+    f3 vs = mk3(cam.viewscreen[0], cam.viewscreen[1], cam.viewscreen[2]);
+    f3 vx = mk3(cam.viewscreen_x[0], cam.viewscreen_x[1], cam.viewscreen_x[2]);
+    f3 vy = mk3(cam.viewscreen_y[0], cam.viewscreen_y[1], cam.viewscreen_y[2]);
+    f3 p = vs + fx * vx + fy * vy;
+    o = mk3(cam.origin[0], cam.origin[1], cam.origin[2]);
+    if (cam.lens_size != 0.0f) {
+        float2 dsc = disc_uniform(lens);
+        float lx = dsc.x * cam.lens_size, ly = dsc.y * cam.lens_size;
+        o = o + lx * mk3(cam.left[0], cam.left[1], cam.left[2]) + ly * mk3(cam.up[0], cam.up[1], cam.up[2]);
+    }
+    d = norm3(p - o);
+}
+
+__global__ __launch_bounds__(256) void k_raygen(const DevScene sc, const DevCamera cam, const PassParams pp, float4* __restrict__ rayA,
+                                                 float4* __restrict__ rayB, float4* __restrict__ thr, float4* __restrict__ tot) {
+    const uint32_t n = pp.npix * pp.ns;
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n; slot += gridDim.x * blockDim.x) {
+        uint32_t srel = slot / pp.npix, j = slot - srel * pp.npix;
+        uint32_t pix = pp.pix_xy[pp.j0 + j], seed = pp.pix_seed[pp.j0 + j];
+        uint32_t s = pp.s0 + srel;
+        float2 jit = sample2d(sc, seed, s, 0);
+        float2 lens = make_float2(0.f, 0.f);
+        if (cam.lens_size != 0.0f) lens = sample2d(sc, seed, s, 1);
+        f3 o, d;
+        camera_ray(cam, (int)(pix & 0xffff), (int)(pix >> 16), (int)pp.xres, (int)pp.yres, jit, lens, o, d);
+        rayA[slot] = make_float4(o.x, o.y, o.z, d.x);
+        rayB[slot] = make_float4(d.y, d.z, __uint_as_float(0xffffffffu), __uint_as_float(slot));
+        thr[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(1u << 16)); // n = 0, 1-D counter = 1
+        tot[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// ------------------------------------------------------------------ K3+K4+K6+K7: shade
+__device__ __forceinline__ f3 clamp3(f3 v, float c) { return mk3(v.x > c ? c : v.x, v.y > c ? c : v.y, v.z > c ? c : v.z); }
+
+__global__ __launch_bounds__(RGK_SHADE_BLOCK) void k_shade(const DevScene sc, const DevCamera cam, const PassParams pp, const uint32_t bounce,
+                                                            const float4* __restrict__ rayA, const float4* __restrict__ rayB,
+                                                            const float4* __restrict__ hit, float4* __restrict__ thr, float4* __restrict__ tot,
+                                                            float4* __restrict__ nextA, float4* __restrict__ nextB, float4* __restrict__ shA,
+                                                            float4* __restrict__ shB, float4* __restrict__ shC, uint32_t* __restrict__ counters) {
+    const uint32_t count = counters[RGK_CNT_QUEUE + bounce];
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const float eps = sc.epsilon;
+    for (uint32_t base = wave * 64; base < count; base += nwaves * 64) {
+        const uint32_t i = base + lane;
+        const bool valid = i < count;
+        bool cont = false, shadow = false;
+        float4 nA = make_float4(0, 0, 0, 0), nB = nA, sA = nA, sB = nA, sC = nA;
+        if (valid) {
+            const float4 a = rayA[i], b = rayB[i], h = hit[i];
+            const uint32_t slot = __float_as_uint(b.w);
+            const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
+            float4 st = thr[slot];
+            f3 cum = mk3(st.x, st.y, st.z);
+            uint32_t bits = __float_as_uint(st.w);
+            uint32_t n = (bits & 0xffffu) + 1u; // n++ at loop top, reference path_tracer.cpp:123
+            uint32_t c1 = bits >> 16;
+            const int tri = __float_as_int(h.w);
+            const uint32_t srel = slot / pp.npix, j = slot - srel * pp.npix;
+            const uint32_t seed = pp.pix_seed[pp.j0 + j];
+            const uint32_t s = pp.s0 + srel;
+            const uint32_t base2d = (cam.lens_size != 0.0f) ? 2u : 1u;
+            const f3 Vr = -d;
+            if (tri < 0) {
+                // sky vertex: path_total += contribution * sky, reference path_tracer.cpp:137-146,409-415
+                f3 sky = skybox(sc, Vr);
+                float4 t = tot[slot];
+                f3 add = cum * sky;
+                t.x = t.x + add.x; t.y = t.y + add.y; t.z = t.z + add.z;
+                tot[slot] = t;
+            } else {
+                const TriShade ts = sc.tri_shade[tri];
+                const float al = h.y, be = h.z;
+                const float ia = 1.0f - al - be, ib = al, ic = be; // Intersection::a,b,c scene_intersect.cpp:280-283
+                const float4* vtx = reinterpret_cast<const float4*>(sc.vtx);
+                const float4 va0 = vtx[2 * ts.va], va1 = vtx[2 * ts.va + 1];
+                const float4 vb0 = vtx[2 * ts.vb], vb1 = vtx[2 * ts.vb + 1];
+                const float4 vc0 = vtx[2 * ts.vc], vc1 = vtx[2 * ts.vc + 1];
+                f3 pos = o + h.x * d;
+                f3 nA_ = mk3(va0.x, va0.y, va0.z), nB_ = mk3(vb0.x, vb0.y, vb0.z), nC_ = mk3(vc0.x, vc0.y, vc0.z);
+                f3 faceN = ia * nA_ + ib * nB_ + ic * nC_;
+                bool ok = true;
+                if (faceN.x != faceN.x) { // NaN fallbacks, path_tracer.cpp:157-171
+                    faceN = nA_;
+                    if (faceN.x != faceN.x) { faceN = nB_; if (faceN.x != faceN.x) { faceN = nC_; if (faceN.x != faceN.x) ok = false; } }
+                }
+                if (ok && len3(faceN) <= 0.0f) ok = false; // path_tracer.cpp:175
+                if (ok) {
+                    faceN = norm3(faceN);
+                    const DevMaterial mat = sc.materials[ts.mat];
+                    float2 uv = make_float2(0.f, 0.f);
+                    if (sc.has_texcoords) {
+                        uv.x = ia * va0.w + ib * vb0.w + ic * vc0.w;
+                        uv.y = ia * va1.w + ib * vb1.w + ic * vc1.w;
+                    }
+                    f3 lightN = faceN;
+                    if (mat.tex_bump >= 0) { // bump, path_tracer.cpp:204-231
+                        float right, bottom;
+                        tex_slopes(sc, mat.tex_bump, uv, right, bottom);
+                        f3 tangent = ia * mk3(va1.x, va1.y, va1.z) + ib * mk3(vb1.x, vb1.y, vb1.z) + ic * mk3(vc1.x, vc1.y, vc1.z);
+                        if (!(tangent.x * tangent.x + tangent.y * tangent.y + tangent.z * tangent.z < 0.001f)) {
+                            tangent = norm3(tangent);
+                            f3 bitangent = norm3(cross3(faceN, tangent));
+                            f3 tangent2 = cross3(bitangent, faceN);
+                            lightN = norm3(faceN + (tangent2 * right + bitangent * bottom) * pp.bumpmap_scale);
+                            if (lightN.x != lightN.x) lightN = faceN;
+                        }
+                    }
+                    // SystemTransform(lightN, +Z), reference src/glm.hpp:21-24
+                    const quatf g2l = rotation_between(lightN, mk3(0.f, 0.f, 1.f));
+                    const quatf l2g = qinverse(g2l);
+                    const f3 VrL = qrot(g2l, Vr);
+                    // BxDF sample, path_tracer.cpp:243-250
+                    float2 u = sample2d(sc, seed, s, base2d + 3u + (n - 1u));
+                    f3 dirL, weight; bool may_leak;
+                    bxdf_sample(sc, (int)ts.mat, VrL, uv, u, dirL, weight, may_leak);
+                    const bool inside = dirL.z < 0;
+                    f3 dir = qrot(l2g, dirL);
+                    uint32_t n_eff = n;
+                    if (!(dot3(dir, faceN) * dot3(Vr, faceN) > 0) && !may_leak) n_eff += 10000u; // leak, :252-260
+                    const bool no_russian = (mat.flags & RGK_MAT_NO_RUSSIAN) != 0;
+                    const float rc = (!no_russian && pp.russian > 0.0f && n_eff > 1u) ? 1.0f / pp.russian : 1.0f;
+                    const f3 contribution = cum; // excludes this vertex's own coefficients, :135
+                    cum = cum * rc;
+                    cum = cum * weight;
+
+                    // ---- phase 3 for this vertex: NEE to the path's light, :427-460,485-496
+                    {
+                        const float2 areal_s = sample2d(sc, seed, s, base2d);
+                        const float2 choice_s = sample2d(sc, seed, s, base2d + 2u);
+                        const float pick = sample1d(sc, seed, s, 0u);
+                        DLight L = random_light(sc, choice_s, pick, areal_s);
+                        if (L.type == 0) L.pos = L.pos + L.size * sphere_uniform(areal_s); // :339-342
+                        f3 e_front = mk3(0.f, 0.f, 0.f);
+                        if (dot3(faceN, Vr) > 0) e_front = mk3(mat.emission[0], mat.emission[1], mat.emission[2]);
+                        const bool has_e = (e_front.x != 0.f) || (e_front.y != 0.f) || (e_front.z != 0.f);
+                        f3 B = mk3(0.f, 0.f, 0.f);
+                        if (has_e) {
+                            B = clamp3(mk3(0.f, 0.f, 0.f) + e_front, pp.clamp) * contribution;
+                            float4 t = tot[slot];
+                            t.x = t.x + B.x; t.y = t.y + B.y; t.z = t.z + B.z;
+                            tot[slot] = t;
+                        }
+                        if (L.type >= 0) {
+                            const f3 diff = pos - L.pos; // Ray(light.pos, p.pos, 20 eps), src/ray.hpp:15-22
+                            const f3 sd = norm3(diff);
+                            const float slen = len3(diff);
+                            const f3 Vi = norm3(L.pos - pos);
+                            const f3 f = bxdf_value(sc, (int)ts.mat, qrot(g2l, Vi), VrL, uv);
+                            const float G = fabsf(dot3(lightN, Vi)) / dot3(diff, diff);
+                            const float k = L.intensity * light_dir_factor(L, -Vi);
+                            const f3 inc = L.color * mk3(k, k, k);
+                            const f3 out = inc * (f * G);
+                            f3 A = clamp3((mk3(0.f, 0.f, 0.f) + out) + e_front, pp.clamp) * contribution;
+                            f3 rad = has_e ? A - B : A;
+                            if (rad.x != 0.f || rad.y != 0.f || rad.z != 0.f) {
+                                shadow = true;
+                                sA = make_float4(L.pos.x, L.pos.y, L.pos.z, sd.x);
+                                sB = make_float4(sd.y, sd.z, slen - eps * 20.0f, __uint_as_float(slot));
+                                sC = make_float4(rad.x, rad.y, rad.z, 0.0f + eps * 20.0f);
+                            }
+                        }
+                    }
+                    // ---- continuation, path_tracer.cpp:275-300
+                    bool go = !(max3c(cum) < 0.001f);
+                    if (go && !no_russian && pp.russian >= 0.0f) {
+                        float r = sample1d(sc, seed, s, c1);
+                        c1++;
+                        if (r > pp.russian) go = false;
+                    }
+                    if (go && n_eff > pp.depth) go = false;
+                    if (go && !(n_eff < pp.depth)) go = false; // while(n < depth__)
+                    if (go) {
+                        const float sgn = inside ? -1.0f : 1.0f;
+                        f3 no = pos + faceN * eps * 10.0f * sgn;
+                        f3 nd = norm3(norm3(dir)); // normalised by the caller and again by Ray's ctor
+                        cont = true;
+                        nA = make_float4(no.x, no.y, no.z, nd.x);
+                        nB = make_float4(nd.y, nd.z, __int_as_float(tri), __uint_as_float(slot));
+                        thr[slot] = make_float4(cum.x, cum.y, cum.z, __uint_as_float((n & 0xffffu) | (c1 << 16)));
+                    }
+                }
+            }
+        }
+        // ---- K7: wave-level compaction into the next queues
+        {
+            unsigned long long m = __ballot(cont);
+            if (m) {
+                uint32_t total = __popcll(m), off = 0;
+                if (lane == 0) off = atomicAdd(&counters[RGK_CNT_QUEUE + bounce + 1], total);
+                off = __builtin_amdgcn_readfirstlane(off);
+                if (cont) {
+                    uint32_t p = off + __popcll(m & ((1ull << lane) - 1ull));
+                    nextA[p] = nA; nextB[p] = nB;
+                }
+            }
+            unsigned long long ms = __ballot(shadow);
+            if (ms) {
+                uint32_t total = __popcll(ms), off = 0;
+                if (lane == 0) off = atomicAdd(&counters[RGK_CNT_SHADOW + bounce], total);
+                off = __builtin_amdgcn_readfirstlane(off);
+                if (shadow) {
+                    uint32_t p = off + __popcll(ms & ((1ull << lane) - 1ull));
+                    shA[p] = sA; shB[p] = sB; shC[p] = sC;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ K9: resolve
+// final clamp + NaN/negative scrub (path_tracer.cpp:502-507), per-pixel sum over the pass's
+// samples in sample order (RenderPixel :64), then AddPixel when the pixel's last sample is in.
+__global__ __launch_bounds__(256) void k_resolve(const PassParams pp, const float4* __restrict__ tot, float4* __restrict__ pixsum,
+                                                  float* __restrict__ accum_rgb, uint32_t* __restrict__ accum_count) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < pp.npix; j += gridDim.x * blockDim.x) {
+        float4 acc = (pp.s0 == 0) ? make_float4(0.f, 0.f, 0.f, 0.f) : pixsum[pp.j0 + j];
+        for (uint32_t srel = 0; srel < pp.ns; srel++) {
+            float4 t = tot[srel * pp.npix + j];
+            f3 v = clamp3(mk3(t.x, t.y, t.z), pp.clamp);
+            if (v.x != v.x || v.x < 0.0f) v.x = 0.0f;
+            if (v.y != v.y || v.y < 0.0f) v.y = 0.0f;
+            if (v.z != v.z || v.z < 0.0f) v.z = 0.0f;
+            acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z;
+        }
+        if (pp.s0 + pp.ns >= pp.multisample) {
+            uint32_t pix = pp.pix_xy[pp.j0 + j];
+            size_t p = (size_t)(pix >> 16) * pp.xres + (pix & 0xffff);
+            accum_rgb[3 * p + 0] += acc.x;
+            accum_rgb[3 * p + 1] += acc.y;
+            accum_rgb[3 * p + 2] += acc.z;
+            accum_count[p] += pp.multisample;
+        } else {
+            pixsum[pp.j0 + j] = acc;
+        }
+    }
+}
+
+__global__ void k_init_counters(uint32_t* counters, uint32_t n0) {
+    for (uint32_t i = threadIdx.x; i < RGK_CNT_TOTAL; i += blockDim.x) counters[i] = (i == RGK_CNT_QUEUE) ? n0 : 0u;
+}
+
+// rays given as 8 floats {o, d, near, far} (rgk_trace_closest API) -> queue layout
+__global__ void k_pack_rays(uint32_t n, const float* __restrict__ rays, const int32_t* __restrict__ ignore, float4* rayA, float4* rayB, float2* nearfar) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float* r = rays + 8 * (size_t)i;
+        rayA[i] = make_float4(r[0], r[1], r[2], r[3]);
+        rayB[i] = make_float4(r[4], r[5], __int_as_float(ignore ? ignore[i] : -1), __uint_as_float(i));
+        nearfar[i] = make_float2(r[6], r[7]);
+    }
+}
+// Ray(a, b, 20 eps) for Scene::Visibility(a, b)
+__global__ void k_pack_visibility(const DevScene sc, uint32_t n, const float* __restrict__ a, const float* __restrict__ b, float4* shA, float4* shB, float4* shC) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        f3 pa = mk3(a[3 * i], a[3 * i + 1], a[3 * i + 2]), pb = mk3(b[3 * i], b[3 * i + 1], b[3 * i + 2]);
+        f3 diff = pb - pa;
+        f3 d = norm3(diff);
+        float e = sc.epsilon * 20.0f;
+        shA[i] = make_float4(pa.x, pa.y, pa.z, d.x);
+        shB[i] = make_float4(d.y, d.z, len3(diff) - e, __uint_as_float(i));
+        shC[i] = make_float4(0.f, 0.f, 0.f, 0.0f + e);
+    }
+}
+__global__ void k_unpack_hits(uint32_t n, const float4* __restrict__ hit, rgk_hit* out) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float4 h = hit[i];
+        rgk_hit r;
+        r.t = h.x; r.tri = __float_as_int(h.w);
+        r.a = 1.0f - h.y - h.z; r.b = h.y; r.c = h.z;
+        if (r.tri < 0) { r.a = 0.f; r.b = 0.f; r.c = 0.f; }
+        out[i] = r;
+    }
+}
+__global__ void k_sampler_eval(const DevScene sc, uint32_t n, const uint32_t* seed, const uint32_t* index, const uint32_t* dim, int is2d, float* out) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (is2d) { float2 v = sample2d(sc, seed[i], index[i], dim[i]); out[2 * i] = v.x; out[2 * i + 1] = v.y; }
+        else { out[2 * i] = sample1d(sc, seed[i], index[i], dim[i]); out[2 * i + 1] = 0.f; }
+    }
+}
+
+// ------------------------------------------------------------------ launch wrappers (host)
+static inline int trace_grid(int stack) {
+    // LDS-limited residency: STACK*256*4 B per block out of 160 KiB, 256 CUs
+    int per_cu = (160 * 1024) / (stack * RGK_TRACE_BLOCK * 4);
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    return 256 * per_cu;
+}
+
+void rgk_launch_init_counters(hipStream_t st, uint32_t* counters, uint32_t n0) { k_init_counters<<<1, 256, 0, st>>>(counters, n0); }
+
+void rgk_launch_raygen(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, float4* rayA, float4* rayB, float4* thr, float4* tot) {
+    uint32_t n = pp.npix * pp.ns;
+    int grid = (int)((n + 255) / 256);
+    if (grid > 256 * 16) grid = 256 * 16;
+    k_raygen<<<grid, 256, 0, st>>>(sc, cam, pp, rayA, rayB, thr, tot);
+}
+
+void rgk_launch_trace_closest(hipStream_t st, const DevScene& sc, int stack, bool count_stats, const float4* rayA, const float4* rayB,
+                              const float2* nearfar, float4* hit, const uint32_t* count_ptr, uint32_t* fetch, unsigned long long* stats) {
+    int grid = trace_grid(stack);
+#define L(C, S) k_trace_closest<C, S><<<grid, RGK_TRACE_BLOCK, 0, st>>>(sc, rayA, rayB, nearfar, hit, count_ptr, fetch, stats)
+    if (stack <= 32) { if (count_stats) L(true, 32); else L(false, 32); }
+    else { if (count_stats) L(true, 64); else L(false, 64); }
+#undef L
+}
+
+void rgk_launch_trace_shadow(hipStream_t st, const DevScene& sc, int stack, bool count_stats, const float4* shA, const float4* shB,
+                             const float4* shC, float4* tot, uint8_t* vis_out, const uint32_t* count_ptr, uint32_t* fetch,
+                             unsigned long long* stats) {
+    int grid = trace_grid(stack);
+#define L(C, S) k_trace_shadow<C, S><<<grid, RGK_TRACE_BLOCK, 0, st>>>(sc, shA, shB, shC, tot, vis_out, count_ptr, fetch, stats)
+    if (stack <= 32) { if (count_stats) L(true, 32); else L(false, 32); }
+    else { if (count_stats) L(true, 64); else L(false, 64); }
+#undef L
+}
+
+void rgk_launch_shade(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t bounce, const float4* rayA,
+                      const float4* rayB, const float4* hit, float4* thr, float4* tot, float4* nextA, float4* nextB, float4* shA,
+                      float4* shB, float4* shC, uint32_t* counters) {
+    k_shade<<<256 * 8, RGK_SHADE_BLOCK, 0, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
+}
+
+void rgk_launch_resolve(hipStream_t st, const PassParams& pp, const float4* tot, float4* pixsum, float* accum_rgb, uint32_t* accum_count) {
+    int grid = (int)((pp.npix + 255) / 256);
+    if (grid > 256 * 16) grid = 256 * 16;
+    k_resolve<<<grid, 256, 0, st>>>(pp, tot, pixsum, accum_rgb, accum_count);
+}
+
+void rgk_launch_pack_rays(hipStream_t st, uint32_t n, const float* rays, const int32_t* ignore, float4* rayA, float4* rayB, float2* nearfar) {
+    k_pack_rays<<<(n + 255) / 256, 256, 0, st>>>(n, rays, ignore, rayA, rayB, nearfar);
+}
+void rgk_launch_pack_visibility(hipStream_t st, const DevScene& sc, uint32_t n, const float* a, const float* b, float4* shA, float4* shB, float4* shC) {
+    k_pack_visibility<<<(n + 255) / 256, 256, 0, st>>>(sc, n, a, b, shA, shB, shC);
+}
+void rgk_launch_unpack_hits(hipStream_t st, uint32_t n, const float4* hit, rgk_hit* out) { k_unpack_hits<<<(n + 255) / 256, 256, 0, st>>>(n, hit, out); }
+void rgk_launch_sampler_eval(hipStream_t st, const DevScene& sc, uint32_t n, const uint32_t* seed, const uint32_t* index, const uint32_t* dim,
+                             int is2d, float* out) {
+    k_sampler_eval<<<(n + 255) / 256, 256, 0, st>>>(sc, n, seed, index, dim, is2d, out);
+}

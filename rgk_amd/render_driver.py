@@ -1,0 +1,191 @@
+"""Host-side mirror of the reference's render driver, over the C ABI.
+
+Mirrors (names, argument meaning, behaviour) reference src/render_driver.cpp:
+  GenerateTaskList :30-46, RenderDriver::RenderRound :144-190, RenderDriver::RenderFrame
+  :192-253 (rounds mode and timed mode), and EXRTexture's accumulator half
+  (src/texture.cpp:342-354,376-412: AddPixel / GetPixel / Normalize / Accumulate).
+
+The reference runs tiles on a CPU thread pool inside one process.  Here the per-task
+body runs on the GPU behind `rgk_render_round*`; with world_size > 1 (one process per
+GPU, torch.distributed) tile i of the centre-out list goes to rank i % world_size and
+the per-GPU private accumulators are summed with one reduce per round
+(EXRTexture::Accumulate under the mutex, render_driver.cpp:179-182, becomes the RCCL
+reduce).  Seeds depend only on (round, tile index, pixel-in-tile): the image does not
+depend on the number of GPUs.
+"""
+import ctypes as C
+import time
+
+import numpy as np
+
+from . import capi
+
+TILE_SIZE = 32  # src/global_config.hpp:8
+SEEDSTART = 42  # src/render_driver.cpp:222
+
+
+def generate_task_list(xres, yres, seedstart=SEEDSTART, seedcount_base=0, tile_size=TILE_SIZE, mid=None):
+    """GenerateTaskList + the `seedstart + c` each task's PathTracer gets."""
+    lib = capi.load_product()
+    mid = mid or (xres / 2.0, yres / 2.0)
+    n = C.c_uint32(0)
+    capi.check(lib, lib.rgk_generate_task_list(tile_size, xres, yres, mid[0], mid[1], seedstart, seedcount_base, None, C.byref(n)))
+    tiles = (capi.Tile * n.value)()
+    capi.check(lib, lib.rgk_generate_task_list(tile_size, xres, yres, mid[0], mid[1], seedstart, seedcount_base, tiles, C.byref(n)))
+    return tiles
+
+
+def shard_tiles(tiles, rank, world_size):
+    """Round-robin deal of the centre-out list: tile i -> rank i % world_size."""
+    idx = list(range(rank, len(tiles), world_size))
+    out = (capi.Tile * len(idx))()
+    for k, i in enumerate(idx):
+        out[k] = tiles[i]
+    return out
+
+
+class Scene:
+    """Device-resident committed scene (rgk_scene_create)."""
+
+    def __init__(self, builder_or_desc, device=0):
+        self.lib = capi.load_product()
+        self._builder = builder_or_desc if hasattr(builder_or_desc, "to_desc") else None
+        desc = builder_or_desc.to_desc() if self._builder is not None else builder_or_desc
+        h = C.c_void_p()
+        capi.check(self.lib, self.lib.rgk_scene_create(C.byref(desc), device, C.byref(h)))
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rgk_scene_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def info(self):
+        i = capi.SceneInfo()
+        capi.check(self.lib, self.lib.rgk_scene_get_info(self.h, C.byref(i)))
+        return i
+
+    def trace_closest(self, rays, ignore=None, count=False):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = len(rays)
+        ig = None if ignore is None else np.ascontiguousarray(ignore, dtype=np.int32)
+        hits = np.zeros(n, dtype=[("t", "f4"), ("tri", "i4"), ("a", "f4"), ("b", "f4"), ("c", "f4")])
+        cnt = capi.Counters()
+        capi.check(self.lib, self.lib.rgk_trace_closest(self.h, n, rays.ctypes.data, None if ig is None else ig.ctypes.data,
+                                                        hits.ctypes.data, C.byref(cnt) if count else None))
+        return hits, cnt
+
+    def visibility(self, a, b, count=False):
+        a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1, 3)
+        b = np.ascontiguousarray(b, dtype=np.float32).reshape(-1, 3)
+        vis = np.zeros(len(a), dtype=np.uint8)
+        cnt = capi.Counters()
+        capi.check(self.lib, self.lib.rgk_trace_visibility(self.h, len(a), a.ctypes.data, b.ctypes.data, vis.ctypes.data,
+                                                           C.byref(cnt) if count else None))
+        return vis, cnt
+
+    def render_round(self, camera, params, tiles, accum=None, count=None):
+        """Host-buffer entry point: accum (yres, xres, 3) float32 +=, count (yres, xres) uint32 +=."""
+        if accum is None:
+            accum = np.zeros((params.yres, params.xres, 3), dtype=np.float32)
+            count = np.zeros((params.yres, params.xres), dtype=np.uint32)
+        cnt = capi.Counters()
+        capi.check(self.lib, self.lib.rgk_render_round(self.h, C.byref(camera), C.byref(params), tiles, len(tiles),
+                                                       accum.ctypes.data, count.ctypes.data, C.byref(cnt)))
+        return accum, count, cnt
+
+    def render_round_device(self, camera, params, tiles, d_accum_ptr, d_count_ptr):
+        cnt = capi.Counters()
+        capi.check(self.lib, self.lib.rgk_render_round_device(self.h, C.byref(camera), C.byref(params), tiles, len(tiles),
+                                                              d_accum_ptr, d_count_ptr, C.byref(cnt)))
+        return cnt
+
+
+def sampler_eval(seed, index, dim, is2d):
+    lib = capi.load_product()
+    seed = np.ascontiguousarray(seed, dtype=np.uint32)
+    index = np.ascontiguousarray(index, dtype=np.uint32)
+    dim = np.ascontiguousarray(dim, dtype=np.uint32)
+    out = np.zeros((len(seed), 2), dtype=np.float32)
+    capi.check(lib, lib.rgk_sampler_eval(len(seed), seed.ctypes.data, index.ctypes.data, dim.ctypes.data, int(is2d), out.ctypes.data))
+    return out
+
+
+class EXRTexture:
+    """The Radiance accumulator (reference src/texture.hpp:83-118); device-resident torch tensors."""
+
+    def __init__(self, xsize, ysize, device):
+        import torch
+        self.xsize, self.ysize = xsize, ysize
+        self.data = torch.zeros((ysize, xsize, 3), dtype=torch.float32, device=device)
+        self.count = torch.zeros((ysize, xsize), dtype=torch.int32, device=device)  # bit pattern of uint32
+
+    def get_pixels(self):
+        """EXRTexture::GetPixel for every pixel: data / count, 0 where count == 0 (texture.cpp:349-354)."""
+        import torch
+        c = self.count.to(torch.float32).unsqueeze(-1)
+        return torch.where(c > 0, self.data / c.clamp(min=1), torch.zeros_like(self.data))
+
+    def normalize(self, val):
+        """EXRTexture::Normalize (texture.cpp:376-400): val <= 0 -> scale so the brightest channel is 1 (Q17)."""
+        px = self.get_pixels()
+        if val <= 0.0:
+            val = 1.0 / float(px.max())
+        return px * val
+
+
+class RenderDriver:
+    """RenderDriver::RenderFrame / RenderRound for one process per GPU."""
+
+    def __init__(self, scene, cfg, camera, rank=0, world_size=1, device=None, sampler=capi.SAMPLER_HALTON, flags=0):
+        import torch
+        self.scene, self.cfg, self.camera = scene, cfg, camera
+        self.rank, self.world_size = rank, world_size
+        self.device = device if device is not None else torch.device("cuda", scene.device)
+        self.params = cfg.get_params(sampler=sampler, flags=flags)
+        self.tasks = generate_task_list(cfg.xres, cfg.yres, SEEDSTART, 0)
+        self.n_tasks = len(self.tasks)
+        self.seedcount = 0
+        self.total_ob = EXRTexture(cfg.xres, cfg.yres, self.device)
+        self.rounds_done = 0
+        self.counters = []
+
+    def render_round(self, reduce=True):
+        """One RenderRound: every rank renders its tiles into its private accumulator, then one
+        sum-reduce to rank 0 (no data-path collective inside the round)."""
+        import torch
+        tiles = generate_task_list(self.cfg.xres, self.cfg.yres, SEEDSTART, self.seedcount)
+        self.seedcount += len(tiles)  # `c = seedcount++` per task, render_driver.cpp:160
+        mine = shard_tiles(tiles, self.rank, self.world_size) if self.world_size > 1 else tiles
+        if self.world_size > 1:
+            ob = EXRTexture(self.cfg.xres, self.cfg.yres, self.device)
+        else:
+            ob = self.total_ob
+        torch.cuda.current_stream(self.device).synchronize()
+        cnt = self.scene.render_round_device(self.camera, self.params, mine, ob.data.data_ptr(), ob.count.data_ptr())
+        if self.world_size > 1 and reduce:
+            import torch.distributed as dist
+            dist.reduce(ob.data, dst=0, op=dist.ReduceOp.SUM)
+            dist.reduce(ob.count, dst=0, op=dist.ReduceOp.SUM)
+            if self.rank == 0:
+                self.total_ob.data += ob.data
+                self.total_ob.count += ob.count
+        self.rounds_done += 1
+        self.counters.append(cnt)
+        return cnt
+
+    def render_frame(self, rounds=None, minutes=None):
+        """RenderFrame: Rounds mode (render_driver.cpp:229-235) or Timed mode (:237-247)."""
+        rounds = self.cfg.render_rounds if rounds is None else rounds
+        minutes = self.cfg.render_minutes if minutes is None else minutes
+        t0 = time.time()
+        if minutes is None:
+            for _ in range(rounds):
+                self.render_round()
+        else:
+            while (time.time() - t0) / 60.0 < minutes:
+                self.render_round()
+        return self.total_ob

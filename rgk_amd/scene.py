@@ -399,6 +399,41 @@ class SceneBuilder:
         self.FM = np.ascontiguousarray(np.concatenate(self.tri_mat), dtype=np.uint32) if self.tri_mat else np.zeros(0, np.uint32)
         return self
 
+    # ---- flat-array fixtures (tests/golden/*.npz): the built scene, no pickles -------------
+    def save_npz(self, path, extra=None):
+        import json
+        self.finalize()
+        meta = dict(materials=self.materials, pointlights=self.pointlights, areal=self.areal, sky=self.sky,
+                    geometry_label=self.geometry_label,
+                    textures=[dict(kind=t["kind"], color=t["color"]) for t in self.textures], extra=extra or {})
+        arrays = dict(V=self.V, N=self.N, T=self.T, UV=self.UV, F=self.F, FM=self.FM,
+                      meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8))
+        for i, t in enumerate(self.textures):
+            if t["kind"] == capi.TEX_RGB32F:
+                arrays[f"tex{i}"] = t["data"]
+        np.savez_compressed(path, **arrays)
+
+    @classmethod
+    def load_npz(cls, path):
+        import json
+        z = np.load(path, allow_pickle=False)
+        meta = json.loads(bytes(z["meta"]).decode())
+        sb = cls()
+        sb.vertices, sb.normals, sb.tangents, sb.texcoords = [z["V"]], [z["N"]], [z["T"]], [z["UV"]]
+        sb.tri_idx, sb.tri_mat = [z["F"]], [z["FM"]]
+        sb.n_verts, sb.n_tris = len(z["V"]), len(z["F"])
+        sb.materials = meta["materials"]
+        for m in sb.materials:
+            m["emission"] = tuple(m["emission"])
+        sb.mat_by_name = {m["name"]: i for i, m in enumerate(sb.materials)}
+        sb.pointlights, sb.areal, sb.sky = meta["pointlights"], meta["areal"], meta["sky"]
+        sb.geometry_label = meta.get("geometry_label", "real")
+        sb.textures = [dict(kind=t["kind"], color=tuple(t["color"]),
+                            data=(np.ascontiguousarray(z[f"tex{i}"]) if t["kind"] == capi.TEX_RGB32F else None))
+                       for i, t in enumerate(meta["textures"])]
+        sb.extra = meta.get("extra", {})
+        return sb.finalize()
+
     def uses_ltc(self):
         return any(m["kind"] >= capi.BXDF_LTC_BECKMANN for m in self.materials)
 

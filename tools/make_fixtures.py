@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Generate the committed fixtures under tests/golden/ (run in the build container only;
+needs /root/reference).  Fixtures are DATA: inputs and expected outputs.
+
+  halton_faure.npz   HS::Halton_sampler::sample(dim, index) after init_faure() from the
+                     reference's own external/halton_sampler.h, compiled where it lies
+                     (oracle/_ref/halton_ref): 256 dims x (256 leading + 64 large indices).
+  cornell_scene.npz  the flat arrays ConfigJSON::Install* would hand to Scene for
+                     scenes/cornell-box.json (built by rgk_amd.config from the reference's
+                     config file), plus camera / render parameters.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+REF = os.environ.get("RGK_REFERENCE", "/root/reference")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def halton():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    rng = np.random.default_rng(20261004)
+    idx = np.concatenate([np.arange(256, dtype=np.uint64), rng.integers(0, 2 ** 32, 64, dtype=np.uint64)]).astype(np.uint32)
+    out = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "halton_ref"), "256"] + [str(int(i)) for i in idx],
+                         capture_output=True, check=True).stdout
+    vals = np.frombuffer(out, dtype=np.float32).reshape(256, len(idx))
+    np.savez_compressed(os.path.join(GOLD, "halton_faure.npz"), index=idx, values=vals)
+    print("halton_faure.npz", vals.shape)
+
+
+def cornell():
+    from rgk_amd.config import Config
+    cfg = Config(os.path.join(REF, "scenes", "cornell-box.json"))
+    sb = cfg.build_scene()
+    cam = cfg.get_camera()
+    extra = dict(camera=dict(pos=list(cam.pos), lookat=list(cam.lookat), up=list(cam.up), fov=19.5),
+                 xres=cfg.xres, yres=cfg.yres, multisample=cfg.multisample, depth=cfg.recursion_level,
+                 clamp=float(cfg.clamp), russian=float(cfg.russian), bumpscale=float(cfg.bumpmap_scale),
+                 reverse=cfg.reverse, source="scenes/cornell-box.json")
+    sb.save_npz(os.path.join(GOLD, "cornell_scene.npz"), extra)
+    print("cornell_scene.npz", len(sb.V), "vertices", len(sb.F), "triangles")
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    halton()
+    cornell()
