@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpaths/s of the path-tracing hot path on MI355X (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload sponza-1080p]
+  N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one RenderRound of the workload: every pixel of the frame gets `multisample`
+paths (raygen -> [trace -> shade -> shadow]*depth -> resolve on the GPU), followed, for
+N > 1, by the RCCL sum-reduce of the per-GPU accumulators to rank 0.  Inputs (scene, BVH,
+textures, tile list) are resident in HBM before the timed region; the accumulator stays
+on the device.
+
+N = 1 workload = the configuration BASELINE.json's metric is quoted on: Sponza
+1920x1080x256spp (scenes/sponza.json + overrides), on the labelled PROXY geometry because
+sponza.obj is absent from the reference checkout.  Scaling is "weak" by
+default: with N GPUs the round takes N x the samples per pixel and the centre-out tile
+list is dealt round-robin, so each GPU traces as many paths as the single GPU does at
+N = 1 (`--scaling strong` keeps the frame's sample count fixed instead).
+
+The JSON line also carries `roofline` for the dominant kernel (k_trace_closest: HIP-event
+time inside the timed region; algorithmic bytes per SURVEY 8(d)) and, at N = 1,
+`cpu_baseline` (the CPU oracle timed on the host cores on a bounded tile sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def host_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+        except (OSError, ValueError, IndexError):
+            pass
+    cap = os.environ.get("RGK_CPU_THREADS")
+    return int(cap) if cap else n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="sponza-1080p")
+    ap.add_argument("--scale", type=float, default=1.0, help="resolution scale (testing only; invalidates the number)")
+    ap.add_argument("--spp", type=int, default=None, help="override samples per pixel (testing only)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from rgk_amd import capi
+    from rgk_amd import render_driver as rd
+    from rgk_amd.workloads import Workload
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    wl = Workload(args.workload, scale=args.scale, spp=args.spp)
+    base_spp = wl.multisample
+    if args.scaling == "weak" and world > 1:
+        wl.multisample = base_spp * world
+    scene = rd.Scene(wl.builder.to_desc(), device=local_rank)
+    info = scene.info()
+
+    class Cfg:  # what RenderDriver needs from Config
+        xres, yres, render_rounds, render_minutes = wl.xres, wl.yres, 1, None
+
+        @staticmethod
+        def get_params(sampler=capi.SAMPLER_HALTON, flags=0):
+            return wl.params(sampler, flags)
+
+    drv = rd.RenderDriver(scene, Cfg, wl.camera, rank=rank, world_size=world, device=device, flags=capi.FLAG_TIME_KERNELS)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        drv.render_round()
+    barrier()
+    t0 = time.perf_counter()
+    cnts = [drv.render_round() for _ in range(args.steps)]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # whole-job unit counts (all ranks)
+    local = np.array([sum(c.paths for c in cnts), sum(c.path_rays for c in cnts), sum(c.shadow_rays for c in cnts)], dtype=np.float64)
+    if world > 1:
+        t = torch.tensor(local, dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        tot = t.cpu().numpy()
+    else:
+        tot = local
+    paths, path_rays, shadow_rays = tot
+
+    # ---- roofline of the dominant kernel (rank 0's launches): traversal counters from one
+    # extra untimed counting round (deterministic per seed), HIP-event time from the timed steps
+    ms_trace = sum(c.ms_trace for c in cnts)
+    n_launch = sum(c.n_trace_launches for c in cnts)
+    rays_local = sum(c.path_rays for c in cnts)
+    drv_c = rd.RenderDriver(scene, Cfg, wl.camera, rank=rank, world_size=world, device=device, flags=capi.FLAG_COUNT_TRAVERSAL)
+    cc = drv_c.render_round(reduce=False)
+    nodes_per_ray = cc.node_visits / max(1, cc.path_rays)
+    tris_per_ray = cc.tri_tests / max(1, cc.path_rays)
+    # per closest-hit ray 32 (ray) + 4 (ignore id) + 16 (hit) + N_node*s_node + N_tri*s_tri
+    bytes_per_ray = 32 + 4 + 16 + nodes_per_ray * info.node_bytes + tris_per_ray * info.tri_bytes
+    alg_bytes = bytes_per_ray * rays_local
+    achieved = alg_bytes / (ms_trace * 1e-3) / 1e9 if ms_trace > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "k_trace_closest", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(achieved / 8000.0, 4), "traffic": None,
+                "launches": n_launch, "avg_launch_ms": round(ms_trace / max(1, n_launch), 4),
+                "alg_bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(nodes_per_ray, 2),
+                "tris_per_ray": round(tris_per_ray, 2), "node_bytes": info.node_bytes, "tri_bytes": info.tri_bytes,
+                "other_kernels_ms": {"k_trace_shadow": round(sum(c.ms_shadow for c in cnts), 2),
+                                     "k_shade": round(sum(c.ms_shade for c in cnts), 2),
+                                     "raygen_resolve": round(sum(c.ms_other for c in cnts), 2)}}
+
+    out = {
+        "metric": "Mpaths/s, Sponza 1920x1080x256spp (path-tracing hot path)",
+        "value": round(paths / elapsed / 1e6, 2), "unit": "Mpaths/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload} {wl.xres}x{wl.yres}x{wl.multisample}spp depth {wl.depth} russian {wl.russian:.2f}",
+                   "geometry": wl.geometry, "triangles": int(len(wl.builder.F)), "sampler": "halton-cp",
+                   "tiles": drv.n_tasks, "parallelism": f"tiles round-robin over {world} GPU(s) + RCCL reduce"},
+        "mrays_per_s_path": round(path_rays / elapsed / 1e6, 2),
+        "mrays_per_s_all": round((path_rays + shadow_rays) / elapsed / 1e6, 2),
+        "roofline": roofline,
+    }
+
+    # ---- CPU baseline: the oracle on the host cores, rank 0 at N = 1 only, bounded sample
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import rgk_oracle as O
+        osc = O.OracleScene(wl.builder.to_desc())
+        threads = max(1, host_cores() - 1)  # hardware_concurrency() - 1, render_driver.cpp:205-206
+        otiles = O.generate_task_list(wl.xres, wl.yres)
+        prm = wl.params()
+
+        def run(n_tiles, sampler):
+            p = wl.params(sampler)
+            sub = (capi.Tile * n_tiles)(*[otiles[i] for i in range(n_tiles)])
+            t = time.perf_counter()
+            _, _, c = osc.render_round(wl.camera, p, sub, n_threads=threads)
+            return c, time.perf_counter() - t
+        n_probe = min(len(otiles), threads)
+        c, dt = run(n_probe, capi.SAMPLER_HALTON)
+        n_tiles = int(max(n_probe, min(len(otiles), n_probe * args.cpu_seconds / max(dt, 1e-3))))
+        n_tiles = max(threads, (n_tiles // threads) * threads)
+        n_tiles = min(n_tiles, len(otiles))
+        c, dt = run(n_tiles, capi.SAMPLER_HALTON)
+        cs, dts = run(max(threads, n_tiles // 4), capi.SAMPLER_STRATIFIED)
+        out["cpu_baseline"] = {
+            "value": round(c.paths / dt / 1e6, 3), "unit": "Mpaths/s", "cores": threads, "kind": "port",
+            "sample": f"first {n_tiles} of {len(otiles)} centre-out 32x32 tiles at {wl.multisample} spp, {dt:.1f} s, shared Halton sampler",
+            "mrays_per_s_path": round(c.path_rays / dt / 1e6, 3),
+            "faithful_sampler_value": round(cs.paths / dts / 1e6, 3),
+            "faithful_sampler_note": "same tiles/4 with the reference's per-pixel mt19937 StratifiedSampler table (src/sampler.cpp:85-116)",
+        }
+        del prm
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -144,6 +144,14 @@ def load_product():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        # One HIP runtime per process: when PyTorch-ROCm is going to share the device (accumulator
+        # tensors, RCCL) its bundled libamdhip64 must be the one the loader resolves for us too,
+        # so import it first; without torch the system ROCm runtime is used.
+        if os.environ.get("RGK_NO_TORCH") != "1":
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         _product = _bind(C.CDLL(LIB_PATH))
     return _product
 

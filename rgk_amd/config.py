@@ -147,16 +147,19 @@ def fov2xview(fov):
 class Config:
     """Scalar fields of reference `Config` (src/config.hpp:27-44) + the parsed root."""
 
-    def __init__(self, path, overrides=None):
+    def __init__(self, path, overrides=None, root=None):
         self.config_file_path = path
-        try:
-            text = open(path).read()
-        except OSError:
-            raise ConfigFileException("Failed to open file: " + path)
-        try:
-            root = json.loads(strip_json_comments(text))
-        except json.JSONDecodeError as e:
-            raise ConfigFileException("Failed to parse JSON contents: " + str(e))
+        if root is None:
+            try:
+                text = open(path).read()
+            except OSError:
+                raise ConfigFileException("Failed to open file: " + path)
+            try:
+                root = json.loads(strip_json_comments(text))
+            except json.JSONDecodeError as e:
+                raise ConfigFileException("Failed to parse JSON contents: " + str(e))
+        else:
+            root = json.loads(json.dumps(root))
         if overrides:
             root.update(overrides)  # SURVEY F6: BASELINE configs are overrides of the shipped files
         self.root = Node(root, "the config file")

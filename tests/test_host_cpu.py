@@ -1,0 +1,222 @@
+"""CPU suite for the host side: config front-end, C-ABI surface, tile sharding + reduce (gloo)."""
+import ctypes as C
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from rgk_amd import capi
+from rgk_amd.config import Config, ConfigFileException, strip_json_comments
+from rgk_amd.scene import SceneBuilder, primitive_data
+
+from conftest import ROOT
+
+
+# ----------------------------------------------------------------------- C ABI
+def test_library_exports_every_symbol_the_header_declares(product_lib):
+    hdr = open(os.path.join(ROOT, "include", "rgk.h")).read()
+    declared = sorted(set(re.findall(r"\b(rgk_[a-z_]+)\s*\(", hdr)))
+    assert declared == sorted(capi.EXPORTS)
+    for name in declared:
+        assert getattr(product_lib, name) is not None
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """sizeof() of every struct, C compiler vs ctypes mirror."""
+    src = tmp_path / "sz.c"
+    names = ["rgk_material", "rgk_texture", "rgk_pointlight", "rgk_scene_desc", "rgk_camera", "rgk_params", "rgk_tile",
+             "rgk_counters", "rgk_scene_info", "rgk_hit"]
+    src.write_text('#include <stdio.h>\n#include "rgk.h"\nint main(){' +
+                   "".join(f'printf("%zu\\n", sizeof({n}));' for n in names) + "return 0;}")
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    mirrors = [capi.Material, capi.Texture, capi.PointLight, capi.SceneDesc, capi.Camera, capi.Params, capi.Tile,
+               capi.Counters, capi.SceneInfo, capi.Hit]
+    assert sizes == [C.sizeof(m) for m in mirrors]
+
+
+def test_product_task_list_equals_oracle(product_lib, oracle):
+    from rgk_amd import render_driver as rd
+    for (w, h) in ((1920, 1080), (100, 70), (32, 32), (1, 1), (33, 65)):
+        a = rd.generate_task_list(w, h, 42, 7)
+        b = oracle.generate_task_list(w, h, 42, 7)
+        assert len(a) == len(b) == ((w + 31) // 32) * ((h + 31) // 32)
+        assert [(t.x0, t.x1, t.y0, t.y1, t.seed) for t in a] == [(t.x0, t.x1, t.y0, t.y1, t.seed) for t in b]
+
+
+def test_host_argument_errors_need_no_gpu(product_lib):
+    n = C.c_uint32(1)
+    tiles = (capi.Tile * 1)()
+    assert product_lib.rgk_generate_task_list(32, 100, 100, 50.0, 50.0, 42, 0, tiles, C.byref(n)) == -1   # buffer too small
+    assert b"too small" in product_lib.rgk_last_error()
+    assert product_lib.rgk_generate_task_list(0, 100, 100, 50.0, 50.0, 42, 0, None, C.byref(n)) == -1
+    h = C.c_void_p()
+    assert product_lib.rgk_scene_create(None, 0, C.byref(h)) == -1                                        # null descriptor
+    d = capi.SceneDesc()
+    assert product_lib.rgk_scene_create(C.byref(d), 0, C.byref(h)) == -1 and not h.value                  # empty scene
+
+
+def test_product_fails_loudly_without_the_extension(monkeypatch):
+    monkeypatch.setattr(capi, "LIB_PATH", "/nonexistent/librgk_hip.so")
+    monkeypatch.setattr(capi, "_product", None)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        capi.load_product()
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "rgk_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle" not in text.lower() or f in ("capi.py",) and "oracle" not in text, f
+
+
+# ----------------------------------------------------------------------- config front-end (f1, minimal)
+def test_json_comments_and_defaults(tmp_path):
+    p = tmp_path / "s.json"
+    p.write_text('''{ // line comment
+        "output-file": "a.exr", /* block */ "output-width": 64, "output-height": 48,
+        "camera": {"position": [0,1,5], "lookat": [0,1,0], "fov": 30},
+        "materials": [{"name": "m", "brdf": "diffuse", "diffuse255": [255, 128, 0], "emission": [1,2,3]},
+                      {"name": "g", "brdf": "ltc_ggx_diffuse", "exponent": 200, "specular": [0.3,0.3,0.3], "url": "http://x//y"}],
+        "scene": [{"primitive": "cube", "material": "m", "translate": [0,0.5,0]},
+                  {"primitive": "plane", "material": "g", "scale": [4,1,4]}],
+        "lights": [{"position": [0,5,0], "intensity": 10, "color255": [255,255,255]}],
+        "unused-key": 1
+    }''')
+    cfg = Config(str(p))
+    assert (cfg.xres, cfg.yres, cfg.multisample, cfg.recursion_level, cfg.reverse) == (64, 48, 1, 40, 0)
+    assert abs(cfg.russian - 0.74) < 1e-7 and cfg.clamp == 1e7 and cfg.bumpmap_scale == 1.0 and cfg.output_scale == -1.0
+    sb = cfg.build_scene().finalize()
+    assert len(sb.F) == 12 + 2 and len(sb.areal) == 1 and len(sb.areal[0]) == 12
+    m, g = sb.materials
+    assert sb.textures[m["tex_diffuse"]]["color"] == pytest.approx((1.0, 128 / 255, 0.0))
+    assert g["kind"] == capi.BXDF_LTC_GGX_DIFFUSE and g["roughness"] == pytest.approx((2 / 202) ** 0.5)
+    assert sb.textures[g["tex_diffuse"]]["color"] == (0.0, 0.0, 0.0)          # LTC diffuse fallback is black
+    cam = cfg.get_camera()
+    assert cam.yview == pytest.approx(cam.xview * 48 / 64)
+    assert "unused-key" in cfg.perform_post_check() and "url" not in cfg.perform_post_check()
+    assert sb.pointlights[0]["color"] == (1.0, 1.0, 1.0)
+
+
+def test_config_errors(tmp_path):
+    def cfg(d):
+        p = tmp_path / "e.json"
+        p.write_text(json.dumps(d))
+        return Config(str(p))
+    base = {"output-file": "a", "output-width": 8, "output-height": 8}
+    with pytest.raises(ConfigFileException):
+        Config(str(tmp_path / "missing.json"))
+    with pytest.raises(ConfigFileException):
+        cfg({"output-width": 8})
+    with pytest.raises(ConfigFileException):
+        cfg(dict(base, rounds=1, **{"render-time": 2}))
+    c = cfg(dict(base, materials=[{"name": "m", "brdf": "cooktorr"}], scene=[]))
+    with pytest.raises(ConfigFileException, match="Unsupported BRDF"):
+        c.build_scene()
+    c = cfg(dict(base, scene=[{"primitive": "plane", "material": "nope"}]))
+    with pytest.raises(RuntimeError, match="was not defined"):
+        c.build_scene()
+    c = cfg(dict(base))
+    with pytest.raises(ConfigFileException, match="neither"):
+        c.build_scene()
+    assert strip_json_comments('{"a": "x//y" /* c */ } // t') == '{"a": "x//y"  } '
+
+
+def test_builtin_primitives_match_reference_shapes():
+    for kind, ntri in (("plane", 2), ("tri", 1), ("cube", 12)):
+        pos, nrm, uv, tan = primitive_data(kind)
+        assert len(pos) == 3 * ntri
+        tri = pos.reshape(-1, 3, 3)
+        gn = np.cross(tri[:, 2] - tri[:, 0], tri[:, 1] - tri[:, 0])     # CalculatePlane's cross(d1, d0)
+        gn /= np.linalg.norm(gn, axis=1, keepdims=True)
+        assert np.allclose(np.abs(np.sum(gn * nrm.reshape(-1, 3, 3)[:, 0], axis=1)), 1)   # faces are planar, normals axis-aligned
+        assert np.allclose(np.sum(nrm * tan, axis=1), 0)
+    pos, _, uv, _ = primitive_data("plane")
+    assert pos[0].tolist() == [1, 0, 1] and uv[0].tolist() == [1, 1] and pos[3].tolist() == [-1, 0, -1]
+
+
+def test_cornell_fixture_matches_reference_config():
+    ref = "/root/reference/scenes/cornell-box.json"
+    if not os.path.exists(ref):
+        pytest.skip("reference not present on this box")
+    a = Config(ref).build_scene().finalize()
+    b = SceneBuilder.load_npz(os.path.join(ROOT, "rgk_amd", "data", "cornell_scene.npz"))
+    assert np.array_equal(a.V, b.V) and np.array_equal(a.F, b.F) and np.array_equal(a.N, b.N) and np.array_equal(a.FM, b.FM)
+    assert len(a.F) == 36 and len(a.V) == 108 and a.areal == b.areal == [[34], [35]]   # 36 triangles, 2 lights
+
+
+def test_obj_loader_on_reference_meshes():
+    ref = "/root/reference/scenes/cubes/cube3.obj"
+    if not os.path.exists(ref):
+        pytest.skip("reference not present on this box")
+    sb = SceneBuilder()
+    sb.load_obj(ref, np.eye(4, dtype=np.float32))
+    sb.finalize()
+    assert len(sb.F) > 8000 and np.isfinite(sb.N).all() and sb.F.max() < len(sb.V)
+    assert all(m["kind"] == capi.BXDF_LTC_GGX_DIFFUSE for m in sb.materials)
+
+
+# ----------------------------------------------------------------------- multi-GPU path on CPU (gloo, world_size 2)
+def _rank_main(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from oracle import rgk_oracle as O
+    from rgk_amd import render_driver as rd
+    from rgk_amd.workloads import Workload
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    wl = Workload("cornell-256", scale=0.25, spp=4)
+    osc = O.OracleScene(wl.builder.to_desc())
+
+    class HostScene:  # stands in for the GPU scene: same entry point, host pointers, oracle underneath
+        device = 0
+
+        def render_round_device(self, camera, params, tiles, d_accum, d_count):
+            cnt = capi.Counters()
+            O.lib().orc_render_round(osc.h, C.byref(camera), C.byref(params), tiles, len(tiles), d_accum, d_count, C.byref(cnt), 1)
+            return cnt
+
+    class Cfg:
+        xres, yres, render_rounds, render_minutes = wl.xres, wl.yres, 2, None
+        get_params = staticmethod(lambda sampler=0, flags=0: wl.params(sampler, flags))
+    real_tl = rd.generate_task_list
+    rd.generate_task_list = lambda *a, **k: O.generate_task_list(*a, **k)   # host-only twin (needs no HIP runtime)
+    torch.cuda.current_stream = lambda dev=None: type("S", (), {"synchronize": lambda self: None})()
+    drv = rd.RenderDriver(HostScene(), Cfg, wl.camera, rank=rank, world_size=world, device=torch.device("cpu"))
+    drv.render_frame()
+    rd.generate_task_list = real_tl
+    if rank == 0:
+        q.put((drv.total_ob.data.numpy().copy(), drv.total_ob.count.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tile_sharding_and_reduce_world_size_2(oracle):
+    import torch.multiprocessing as mp
+    from rgk_amd.workloads import Workload
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    data, count = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference: two rounds over the whole tile list
+    wl = Workload("cornell-256", scale=0.25, spp=4)
+    osc = oracle.OracleScene(wl.builder.to_desc())
+    acc = np.zeros((wl.yres, wl.xres, 3), np.float32); cnt = np.zeros((wl.yres, wl.xres), np.uint32)
+    n = len(oracle.generate_task_list(wl.xres, wl.yres))
+    for r in range(2):
+        osc.render_round(wl.camera, wl.params(), oracle.generate_task_list(wl.xres, wl.yres, seedcount_base=r * n), acc, cnt)
+    assert np.array_equal(count.view(np.uint32), cnt)
+    assert np.array_equal(data, acc)      # disjoint tiles: the reduce is exact, the image does not depend on G

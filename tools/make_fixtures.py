@@ -5,7 +5,7 @@ needs /root/reference).  Fixtures are DATA: inputs and expected outputs.
   halton_faure.npz   HS::Halton_sampler::sample(dim, index) after init_faure() from the
                      reference's own external/halton_sampler.h, compiled where it lies
                      (oracle/_ref/halton_ref): 256 dims x (256 leading + 64 large indices).
-  cornell_scene.npz  the flat arrays ConfigJSON::Install* would hand to Scene for
+  rgk_amd/data/cornell_scene.npz  the flat arrays ConfigJSON::Install* would hand to Scene for
                      scenes/cornell-box.json (built by rgk_amd.config from the reference's
                      config file), plus camera / render parameters.
 """
@@ -41,7 +41,7 @@ def cornell():
                  xres=cfg.xres, yres=cfg.yres, multisample=cfg.multisample, depth=cfg.recursion_level,
                  clamp=float(cfg.clamp), russian=float(cfg.russian), bumpscale=float(cfg.bumpmap_scale),
                  reverse=cfg.reverse, source="scenes/cornell-box.json")
-    sb.save_npz(os.path.join(GOLD, "cornell_scene.npz"), extra)
+    sb.save_npz(os.path.join(ROOT, "rgk_amd", "data", "cornell_scene.npz"), extra)
     print("cornell_scene.npz", len(sb.V), "vertices", len(sb.F), "triangles")
 
 
