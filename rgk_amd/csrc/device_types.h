@@ -6,16 +6,33 @@
 #include <stdint.h>
 #include "../../include/rgk.h"
 
-#define RGK_NODE_BYTES 64 // BvhNode
+#define RGK_NODE_BYTES 64 // QNode
 #define RGK_TRI_BYTES 48  // TriIsect
 
-// BVH2 node, 64 B = 4 x float4.  Children < 0 are leaves: ~child = (first << 4) | (count - 1),
-// `first` indexing TriIsect records stored in leaf order.
+// Host-side intermediate of the build: binary node with both child boxes.  Children < 0 are
+// leaves: ~child = (first << 4) | (count - 1), `first` indexing TriIsect records in leaf order.
 struct BvhNode {
     float lmin[3], lmax[3]; // left child box
     float rmin[3], rmax[3]; // right child box
     int32_t left, right;
     int32_t pad[2];
+};
+
+// The node the kernels traverse: a 4-wide BVH node in ONE 64-byte line (4 dwordx4 per lane).
+// Child boxes are 8-bit offsets from the node's own box minimum `p`, in units of 2^(e-127) per
+// axis: lo = p + qlo * scale, hi = p + qhi * scale, rounded outward at build time, so a decoded
+// box always contains the (epsilon-padded) child box it stands for.  Box tests only steer the walk;
+// results come from the triangle records, so the quantisation cannot change a hit.
+// child[i] >= 0: inner node index; < 0: leaf, ~child = (first << 4) | (count - 1);
+// RGK_QNODE_EMPTY: unused slot (its box is inverted: qlo = 255, qhi = 0).
+#define RGK_QNODE_EMPTY 0x7fffffff
+struct QNode {
+    float p[3];
+    uint8_t e[3], pad0;
+    int32_t child[4];
+    uint8_t qlo[3][4]; // [axis][child]
+    uint8_t qhi[3][4];
+    uint32_t pad1[2];
 };
 
 // Everything Triangle::TestIntersection (reference src/primitives.cpp:75-166) reads for
@@ -76,6 +93,8 @@ struct DevArealTri {
     uint32_t tri;
     float a[3], b[3], c[3]; // vertices A, B, C of the triangle (GetRandomPoint primitives.cpp:61-73)
     float normal_a[3];      // GetNormalA()
+    uint32_t light;         // index of the DevArealLight this triangle belongs to
+    uint32_t pad;
 };
 
 struct DevHaltonDim { // one Halton dimension of the Faure-permuted sampler
@@ -96,7 +115,7 @@ struct DevCamera {
 };
 
 struct DevScene {
-    const BvhNode* nodes;
+    const QNode* nodes;
     const TriIsect* tris;
     const TriShade* tri_shade;
     const VtxAttr* vtx;

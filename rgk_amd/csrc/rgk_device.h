@@ -131,6 +131,28 @@ __device__ inline float2 sample2d(const DevScene& sc, uint32_t seed, uint32_t in
 __device__ inline float sample1d(const DevScene& sc, uint32_t seed, uint32_t index, uint32_t k) {
     return halton_cp(sc, seed, index, k < 64 ? 3 * k + 2 : 192 + 3 * (k - 64) + 2);
 }
+// The raw Halton value depends on (dimension, sample index) only, not on the pixel: a round
+// tabulates halton_raw once into htab[hdim * S + index] (192 x multisample floats, L2-resident)
+// and every path reads it back -- same bits, no digit walk on the hot path.
+struct SamplerTab {
+    const float* htab;
+    uint32_t S;
+};
+__device__ __forceinline__ float halton_cp_t(const SamplerTab& tb, uint32_t seed, uint32_t index, uint32_t hdim) {
+    if (hdim >= 192) return u01(mix32(mix32(seed ^ hdim_key(hdim)) + index * 0xc2b2ae35u));
+    float u = tb.htab[hdim * tb.S + index] + u01(mix32(seed ^ hdim_key(hdim)));
+    if (u >= 1.0f) u -= 1.0f;
+    return u;
+}
+__device__ __forceinline__ float2 sample2d_t(const SamplerTab& tb, uint32_t seed, uint32_t index, uint32_t k) {
+    uint32_t d = k < 64 ? 3 * k : 192 + 3 * (k - 64);
+    float x = halton_cp_t(tb, seed, index, d);
+    float y = halton_cp_t(tb, seed, index, d + 1);
+    return make_float2(x, y);
+}
+__device__ __forceinline__ float sample1d_t(const SamplerTab& tb, uint32_t seed, uint32_t index, uint32_t k) {
+    return halton_cp_t(tb, seed, index, k < 64 ? 3 * k + 2 : 192 + 3 * (k - 64) + 2);
+}
 
 // ------------------------------------------------------------------ random_utils.hpp:12-73
 __device__ inline float2 disc_uniform(float2 s) {
@@ -235,61 +257,50 @@ __device__ inline LtcM ltc_bilinear(const float* tab, float theta, float alpha) 
     LtcM r;
     r.m0 = RGK_BIL(0); r.m2 = RGK_BIL(1); r.m4 = RGK_BIL(2); r.m6 = RGK_BIL(3); r.amp = RGK_BIL(4);
 #undef RGK_BIL
-    r.m8 = 1.0f * dt2 * da2 + 1.0f * dt2 * da1 + 1.0f * dt1 * da2 + 1.0f * dt1 * da1;
+    r.m8 = dt2 * da2 + dt2 * da1 + dt1 * da2 + dt1 * da1; // the constant-1 entry, interpolated like the rest
     return r;
 }
-// glm::determinant / glm::inverse restricted to the sparsity pattern; every surviving
-// product keeps its position in glm's cofactor expressions (x*0 and x-0 are exact).
-__device__ __forceinline__ float ltc_det(const LtcM& M) {
-    // m[0]=(m0,0,m2) m[1]=(0,m4,0) m[2]=(m6,0,m8)
-    float c00 = M.m4 * M.m8 - 0.0f * 0.0f;
-    float c20 = 0.0f * 0.0f - M.m4 * M.m2;
-    return +M.m0 * c00 - 0.0f * (0.0f * M.m8 - 0.0f * M.m2) + M.m6 * c20;
-}
-// LTC::GetPDF(ltc, N=+Z, Vr=A, Vi=B, alpha), reference src/LTC/ltc.cpp:59-87
-__device__ inline float ltc_pdf(const float* tab, f3 A, f3 B, float alpha) {
-    const f3 N = mk3(0.f, 0.f, 1.f);
-    f3 tangent = cross3(N, B);
-    f3 Bcast = cross3(tangent, N);
-    // rotate = mat3(Bcast, tangent, N); unrotate = inverse(rotate) (general glm formula)
-    float m00 = Bcast.x, m01 = Bcast.y, m02 = Bcast.z;
-    float m10 = tangent.x, m11 = tangent.y, m12 = tangent.z;
-    float m20 = N.x, m21 = N.y, m22 = N.z;
-    float ood = 1.0f / (+m00 * (m11 * m22 - m21 * m12) - m10 * (m01 * m22 - m21 * m02) + m20 * (m01 * m12 - m11 * m02));
-    float i00 = +(m11 * m22 - m21 * m12) * ood, i10 = -(m10 * m22 - m20 * m12) * ood, i20 = +(m10 * m21 - m20 * m11) * ood;
-    float i01 = -(m01 * m22 - m21 * m02) * ood, i11 = +(m00 * m22 - m20 * m02) * ood, i21 = -(m00 * m21 - m20 * m01) * ood;
-    float i02 = +(m01 * m12 - m11 * m02) * ood, i12 = -(m00 * m12 - m10 * m02) * ood, i22 = +(m00 * m11 - m10 * m01) * ood;
-    f3 A3 = mk3(i00 * A.x + i10 * A.y + i20 * A.z, i01 * A.x + i11 * A.y + i21 * A.z, i02 * A.x + i12 * A.y + i22 * A.z);
-    float theta = glm_angle(B, N);
-    LtcM M = ltc_bilinear(tab, theta, alpha);
-    // invM = glm::inverse(M) with m[0]=(m0,0,m2) m[1]=(0,m4,0) m[2]=(m6,0,m8)
+__device__ __forceinline__ float ltc_theta(f3 B) { return glm_angle(B, mk3(0.f, 0.f, 1.f)); }
+
+// LTC::GetPDF(ltc, N=+Z, Vr=A, Vi=B, alpha), reference src/LTC/ltc.cpp:59-87, given the table
+// entry M interpolated at theta = angle(B, N).  The closed forms are glm::inverse / determinant /
+// mat*vec with the structural zeros of M and of the N = +Z frame folded in: every surviving
+// product and sum keeps its place and order in glm's cofactor expressions (x*0 = +-0 and
+// x + +-0 = x for finite x), so the value is bit-identical to the general formulas of the oracle.
+__device__ inline float ltc_pdf_M(const LtcM& M, f3 A, f3 B) {
+    // rotate = mat3((B.x,B.y,0), (-B.y,B.x,0), (0,0,1)); A3 = inverse(rotate) * A
+    float det = B.x * B.x + B.y * B.y;
+    float ood = 1.0f / det;
+    float bxo = B.x * ood, byo = B.y * ood;
+    f3 A3 = mk3(bxo * A.x + byo * A.y, (-byo) * A.x + bxo * A.y, (det * ood) * A.z);
+    // invM * A3 with m[0]=(m0,0,m2) m[1]=(0,m4,0) m[2]=(m6,0,m8)
     float a00 = M.m0, a02 = M.m2, a11 = M.m4, a20 = M.m6, a22 = M.m8;
-    float oodM = 1.0f / (+a00 * (a11 * a22 - 0.0f * 0.0f) - 0.0f * (0.0f * a22 - 0.0f * a02) + a20 * (0.0f * 0.0f - a11 * a02));
-    float j00 = +(a11 * a22 - 0.0f * 0.0f) * oodM, j10 = -(0.0f * a22 - a20 * 0.0f) * oodM, j20 = +(0.0f * 0.0f - a20 * a11) * oodM;
-    float j01 = -(0.0f * a22 - 0.0f * a02) * oodM, j11 = +(a00 * a22 - a20 * a02) * oodM, j21 = -(a00 * 0.0f - a20 * 0.0f) * oodM;
-    float j02 = +(0.0f * 0.0f - a11 * a02) * oodM, j12 = -(a00 * 0.0f - 0.0f * a02) * oodM, j22 = +(a00 * a11 - 0.0f * 0.0f) * oodM;
-    f3 p = norm3(mk3(j00 * A3.x + j10 * A3.y + j20 * A3.z, j01 * A3.x + j11 * A3.y + j21 * A3.z, j02 * A3.x + j12 * A3.y + j22 * A3.z));
-    // L_ = M * p
-    f3 L = mk3(a00 * p.x + 0.0f * p.y + a20 * p.z, 0.0f * p.x + a11 * p.y + 0.0f * p.z, a02 * p.x + 0.0f * p.y + a22 * p.z);
+    float detM = a00 * (a11 * a22) - a20 * (a11 * a02);
+    float oodM = 1.0f / detM;
+    float j00 = (a11 * a22) * oodM, j20 = (-(a20 * a11)) * oodM;
+    float j11 = (a00 * a22 - a20 * a02) * oodM;
+    float j02 = (-(a11 * a02)) * oodM, j22 = (a00 * a11) * oodM;
+    f3 p = norm3(mk3(j00 * A3.x + j20 * A3.z, j11 * A3.y, j02 * A3.x + j22 * A3.z));
+    f3 L = mk3(a00 * p.x + a20 * p.z, a11 * p.y, a02 * p.x + a22 * p.z); // M * p
     float l = len3(L);
-    float detM = ltc_det(M);
     float Jacobian = detM / (l * l * l);
     float D = 1.0f / 3.14159f * fmaxf(0.0f, p.z);
     return M.amp * D / Jacobian;
 }
-// LTC::GetRandom(ltc, N=+Z, Vi, roughness, rand_hscos), reference src/LTC/ltc.cpp:113-143
-__device__ inline f3 ltc_random(const float* tab, f3 Vi, float roughness, f3 rnd) {
-    const f3 N = mk3(0.f, 0.f, 1.f);
-    f3 tangent = cross3(N, Vi);
-    f3 Vc = cross3(tangent, N);
-    float theta = glm_angle(Vi, N);
-    LtcM M = ltc_bilinear(tab, fmaxf(theta, RGK_PI_F / 4.0f), roughness);
-    f3 s = mk3(M.m0 * rnd.x + 0.0f * rnd.y + M.m6 * rnd.z, 0.0f * rnd.x + M.m4 * rnd.y + 0.0f * rnd.z,
-               M.m2 * rnd.x + 0.0f * rnd.y + M.m8 * rnd.z);
+// LTC::GetRandom(ltc, N=+Z, Vi, roughness, rand_hscos), reference src/LTC/ltc.cpp:113-143, given
+// M interpolated at max(theta, pi/4)
+__device__ inline f3 ltc_random_M(const LtcM& M, f3 Vi, f3 rnd) {
+    f3 s = mk3(M.m0 * rnd.x + M.m6 * rnd.z, M.m4 * rnd.y, M.m2 * rnd.x + M.m8 * rnd.z);
     if (s.z < 0.0001f) s.z = 0.0001f;
-    f3 r = mk3(Vc.x * s.x + tangent.x * s.y + N.x * s.z, Vc.y * s.x + tangent.y * s.y + N.y * s.z,
-               Vc.z * s.x + tangent.z * s.y + N.z * s.z);
+    // rotate * s, rotate = mat3((Vi.x,Vi.y,0), (-Vi.y,Vi.x,0), (0,0,1))
+    f3 r = mk3(Vi.x * s.x + (-Vi.y) * s.y, Vi.y * s.x + Vi.x * s.y, s.z);
     return norm3(r);
+}
+__device__ inline float ltc_pdf(const float* tab, f3 A, f3 B, float alpha) {
+    return ltc_pdf_M(ltc_bilinear(tab, ltc_theta(B), alpha), A, B);
+}
+__device__ inline f3 ltc_random(const float* tab, f3 Vi, float roughness, f3 rnd) {
+    return ltc_random_M(ltc_bilinear(tab, fmaxf(ltc_theta(Vi), RGK_PI_F / 4.0f), roughness), Vi, rnd);
 }
 
 // ------------------------------------------------------------------ BxDFs (a11)
@@ -437,11 +448,68 @@ __device__ inline void bxdf_sample(const DevScene& sc, int mat, f3 Vi, float2 uv
     }
 }
 
+// Per-vertex material evaluation with everything `sample` and `value` share fetched once:
+// texture colours at uv, and the LTC table entries (value interpolates at theta, sample at
+// max(theta, pi/4): the same entry whenever theta >= pi/4).  Same values as bxdf_sample /
+// bxdf_value; mirrors, dielectrics, transparents and mixes take the generic route.
+struct MatPrep {
+    bool fast;
+    f3 diffc, colorc;
+    LtcM Mv, Ms;
+};
+__device__ inline void mat_prepare(const DevScene& sc, const DevMaterial& m, float2 uv, f3 VrL, MatPrep& e) {
+    e.fast = false;
+    e.diffc = e.colorc = mk3(0.f, 0.f, 0.f);
+    const uint32_t k = m.kind;
+    if (k == RGK_BXDF_DIFFUSE) {
+        e.fast = true;
+        e.diffc = tex_get(sc, m.tex_diffuse, uv);
+    } else if (k >= RGK_BXDF_LTC_BECKMANN) {
+        e.fast = true;
+        e.colorc = tex_get(sc, m.tex_color, uv);
+        if (k >= RGK_BXDF_LTC_BECKMANN_DIFFUSE) e.diffc = tex_get(sc, m.tex_diffuse, uv);
+        const float* tab = (k == RGK_BXDF_LTC_GGX || k == RGK_BXDF_LTC_GGX_DIFFUSE) ? sc.ltc_ggx : sc.ltc_beckmann;
+        const float theta = ltc_theta(VrL);
+        e.Mv = ltc_bilinear(tab, theta, m.roughness);
+        e.Ms = (theta >= RGK_PI_F / 4.0f) ? e.Mv : ltc_bilinear(tab, RGK_PI_F / 4.0f, m.roughness);
+    }
+}
+__device__ inline void mat_sample(const DevScene& sc, int mat, const DevMaterial& m, const MatPrep& e, f3 VrL, float2 uv, float2 u,
+                                  f3& dir, f3& weight, bool& may_leak) {
+    if (!e.fast) { bxdf_sample(sc, mat, VrL, uv, u, dir, weight, may_leak); return; }
+    may_leak = false;
+    const f3 zero = mk3(0.f, 0.f, 0.f);
+    bool lobe = m.kind != RGK_BXDF_DIFFUSE; // LTC lobe, unless the diffuse branch is chosen below
+    if (m.kind >= RGK_BXDF_LTC_BECKMANN_DIFFUSE) {
+        float dp = e.diffc.x + e.diffc.y + e.diffc.z, sp = e.colorc.x + e.colorc.y + e.colorc.z;
+        float prob = dp / (dp + sp + 0.0001f);
+        if (decide_and_rescale(u.x, prob)) lobe = false;
+    }
+    if (!lobe) {
+        if (VrL.z <= 0) { dir = mk3(0.f, 1.f, 0.f); weight = zero; return; }
+        dir = hemisphere_cosine_z(u);
+        weight = e.diffc;
+        return;
+    }
+    f3 v = ltc_random_M(e.Ms, VrL, hemisphere_cosine_z(u));
+    dir = v;
+    weight = (v.z <= 0) ? zero : e.colorc;
+}
+__device__ inline f3 mat_value(const DevScene& sc, int mat, const DevMaterial& m, const MatPrep& e, f3 ViL, f3 VrL, float2 uv) {
+    if (!e.fast) return bxdf_value(sc, mat, ViL, VrL, uv);
+    if (ViL.z <= 0 || VrL.z <= 0) return mk3(0.f, 0.f, 0.f);
+    if (m.kind == RGK_BXDF_DIFFUSE) return e.diffc / RGK_PI_F;
+    float pdf = ltc_pdf_M(e.Mv, ViL, VrL);
+    if (m.kind >= RGK_BXDF_LTC_BECKMANN_DIFFUSE) return e.colorc * pdf + e.diffc / RGK_PI_F;
+    return e.colorc * pdf;
+}
+
 // ------------------------------------------------------------------ lights / sky (a10, a15)
 struct DLight {
     f3 pos, color, normal;
     float intensity, size;
-    int type; // 0 FULL_SPHERE, 1 HEMISPHERE, -1 none (Q15: zero contribution)
+    int type;  // 0 FULL_SPHERE, 1 HEMISPHERE, -1 none (Q15: zero contribution)
+    int index; // point-light index, or index into areal_tris
 };
 __device__ __forceinline__ float light_dir_factor(const DLight& l, f3 v) {
     return l.type == 0 ? 1.0f : fmaxf(0.0f, dot3(v, l.normal));
@@ -452,7 +520,7 @@ __device__ inline DLight random_light(const DevScene& sc, float2 choice, float l
     DLight L;
     L.type = -1;
     L.pos = L.color = L.normal = mk3(0.f, 0.f, 0.f);
-    L.intensity = 0.f; L.size = 0.f;
+    L.intensity = 0.f; L.size = 0.f; L.index = 0;
     float total_power = sc.total_point_power + sc.total_areal_power;
     if (total_power <= 0.0f) return L;
     float q = choice.x * total_power;
@@ -464,7 +532,7 @@ __device__ inline DLight random_light(const DevScene& sc, float2 choice, float l
                 L.type = 0;
                 L.pos = mk3(pl.pos[0], pl.pos[1], pl.pos[2]);
                 L.color = mk3(pl.color[0], pl.color[1], pl.color[2]);
-                L.intensity = pl.intensity; L.size = pl.size;
+                L.intensity = pl.intensity; L.size = pl.size; L.index = (int)i;
                 return L;
             }
         }
@@ -491,12 +559,49 @@ __device__ inline DLight random_light(const DevScene& sc, float2 choice, float l
                     L.color = mk3(al.emission[0], al.emission[1], al.emission[2]);
                     L.intensity = 1.0f;
                     L.normal = mk3(at->normal_a[0], at->normal_a[1], at->normal_a[2]);
+                    L.index = (int)(al.first + j);
                     return L;
                 }
             }
             return L;
         }
     }
+    return L;
+}
+// The path's light (TracePath picks ONE light per path, path_tracer.cpp:315-322,339-343) is sampled
+// once in k_raygen and kept per slot as {pos.xyz, code}: code = point-light index, or
+// 0x80000000 | areal-triangle index, or RGK_LIGHT_NONE.  Colour / normal / intensity are re-read
+// from the (tiny, cached) light tables.
+#define RGK_LIGHT_NONE 0x7fffffffu
+__device__ inline uint32_t light_code(const DevScene& sc, float2 choice, float light_sample, float2 tri_sample, f3& pos) {
+    DLight L = random_light(sc, choice, light_sample, tri_sample);
+    pos = L.pos;
+    if (L.type < 0) return RGK_LIGHT_NONE;
+    if (L.type == 0) {
+        pos = L.pos + L.size * sphere_uniform(tri_sample); // path_tracer.cpp:339-342 (areal_sample reused)
+        return (uint32_t)L.index;
+    }
+    return 0x80000000u | (uint32_t)L.index;
+}
+__device__ inline DLight light_from_code(const DevScene& sc, f3 pos, uint32_t code) {
+    DLight L;
+    L.pos = pos;
+    L.normal = L.color = mk3(0.f, 0.f, 0.f);
+    L.intensity = 0.f; L.size = 0.f; L.index = 0;
+    if (code == RGK_LIGHT_NONE) { L.type = -1; return L; }
+    if (code & 0x80000000u) {
+        const DevArealTri* at = &sc.areal_tris[code & 0x7fffffffu];
+        const DevArealLight* al = &sc.areal[at->light];
+        L.type = 1;
+        L.color = mk3(al->emission[0], al->emission[1], al->emission[2]);
+        L.intensity = 1.0f;
+        L.normal = mk3(at->normal_a[0], at->normal_a[1], at->normal_a[2]);
+        return L;
+    }
+    const DevPointLight* pl = &sc.pointlights[code];
+    L.type = 0;
+    L.color = mk3(pl->color[0], pl->color[1], pl->color[2]);
+    L.intensity = pl->intensity; L.size = pl->size;
     return L;
 }
 // Scene::GetSkyboxRay, reference src/scene.cpp:748-763

@@ -172,6 +172,85 @@ struct BvhBuilder {
     }
 };
 
+// ------------------------------------------------------------------ BVH2 -> quantised BVH4
+// Collapse the binary tree (always open the inner child with the largest surface until four
+// children) and quantise each child box to 8 bits per plane relative to the node's box, rounding
+// outward and re-checking the decode in float exactly as the kernel evaluates it.
+struct QbvhBuilder {
+    const std::vector<BvhNode>& bn;
+    std::vector<QNode> out;
+    uint32_t max_stack = 0, max_depth = 0;
+    explicit QbvhBuilder(const std::vector<BvhNode>& b) : bn(b) {}
+    struct Child { int ref; Box box; };
+
+    static bool valid(const Box& b) { return b.mn[0] <= b.mx[0] && b.mn[1] <= b.mx[1] && b.mn[2] <= b.mx[2]; }
+    void children_of(int node, Child& l, Child& r) const {
+        const BvhNode& n = bn[node];
+        l.ref = n.left; r.ref = n.right;
+        for (int a = 0; a < 3; a++) { l.box.mn[a] = n.lmin[a]; l.box.mx[a] = n.lmax[a]; r.box.mn[a] = n.rmin[a]; r.box.mx[a] = n.rmax[a]; }
+    }
+    // `stack_before`: entries a traversal may already hold when it reaches this node
+    int collapse(int node, uint32_t depth, uint32_t stack_before) {
+        std::vector<Child> ch(2);
+        children_of(node, ch[0], ch[1]);
+        ch.erase(std::remove_if(ch.begin(), ch.end(), [](const Child& c) { return !valid(c.box); }), ch.end());
+        while (ch.size() < 4) {
+            int best = -1;
+            float best_area = -1.f;
+            for (size_t i = 0; i < ch.size(); i++)
+                if (ch[i].ref >= 0 && ch[i].box.area() > best_area) { best_area = ch[i].box.area(); best = (int)i; }
+            if (best < 0) break;
+            Child a, b;
+            children_of(ch[best].ref, a, b);
+            ch.erase(ch.begin() + best);
+            if (valid(a.box)) ch.push_back(a);
+            if (valid(b.box)) ch.push_back(b);
+        }
+        int idx = (int)out.size();
+        out.emplace_back();
+        max_depth = std::max(max_depth, depth);
+        const uint32_t pushed = (uint32_t)ch.size() - 1;
+        max_stack = std::max(max_stack, stack_before + pushed);
+        Box nb;
+        nb.reset();
+        for (auto& c : ch) nb.grow(c.box);
+        QNode q;
+        std::memset(&q, 0, sizeof(q));
+        for (int a = 0; a < 3; a++) {
+            q.p[a] = nb.mn[a];
+            float ext = nb.mx[a] - nb.mn[a];
+            int e = 0;
+            if (ext > 0.f) { std::frexp(ext / 255.0f, &e); } else e = -126;
+            for (;; e++) { // find the smallest exponent whose outward-rounded codes all fit and verify
+                if (e < -126) e = -126;
+                const float scale = std::ldexp(1.0f, e);
+                bool ok = true;
+                uint8_t lo[4], hi[4];
+                for (size_t i = 0; i < ch.size() && ok; i++) {
+                    float fl = std::floor((ch[i].box.mn[a] - q.p[a]) / scale), fh = std::ceil((ch[i].box.mx[a] - q.p[a]) / scale);
+                    if (fl < 0.f) fl = 0.f;
+                    while (fl > 0.f && std::fmaf(fl, scale, q.p[a]) > ch[i].box.mn[a]) fl -= 1.f;
+                    while (fh <= 255.f && std::fmaf(fh, scale, q.p[a]) < ch[i].box.mx[a]) fh += 1.f;
+                    if (fh > 255.f || fl > 255.f) { ok = false; break; }
+                    lo[i] = (uint8_t)fl; hi[i] = (uint8_t)fh;
+                }
+                if (!ok) continue;
+                q.e[a] = (uint8_t)(e + 127);
+                for (size_t i = 0; i < 4; i++) { q.qlo[a][i] = i < ch.size() ? lo[i] : 255; q.qhi[a][i] = i < ch.size() ? hi[i] : 0; }
+                break;
+            }
+        }
+        for (size_t i = 0; i < 4; i++) q.child[i] = RGK_QNODE_EMPTY;
+        out[idx] = q;
+        for (size_t i = 0; i < ch.size(); i++) {
+            int ref = ch[i].ref;
+            if (ref >= 0) ref = collapse(ref, depth + 1, stack_before + pushed);
+            out[idx].child[i] = ref;
+        }
+        return idx;
+    }
+};
+
 // ------------------------------------------------------------------ scene object
 template <typename T>
 struct DevBuf {
@@ -208,7 +287,7 @@ struct rgk_scene {
     DevScene dev{};
     int stack = 32;
     // scene data
-    DevBuf<BvhNode> nodes;
+    DevBuf<QNode> nodes;
     DevBuf<TriIsect> tris;
     DevBuf<TriShade> tri_shade;
     DevBuf<VtxAttr> vtx;
@@ -223,7 +302,8 @@ struct rgk_scene {
     DevBuf<uint16_t> hperm;
     // workspace
     size_t batch = 0;
-    DevBuf<float4> rayA[2], rayB[2], hit, thr, tot, shA, shB, shC, pixsum;
+    DevBuf<float4> rayA[2], rayB[2], hit, thr, tot, shA, shB, shC, pixsum, light;
+    DevBuf<float> htab;
     DevBuf<float2> nearfar;
     DevBuf<uint32_t> counters, pix_xy, pix_seed;
     DevBuf<unsigned long long> stats;
@@ -240,6 +320,7 @@ struct rgk_scene {
         ltc_beckmann.release(); hdims.release(); hperm.release();
         for (int i = 0; i < 2; i++) { rayA[i].release(); rayB[i].release(); }
         hit.release(); thr.release(); tot.release(); shA.release(); shB.release(); shC.release(); pixsum.release();
+        light.release(); htab.release();
         nearfar.release(); counters.release(); pix_xy.release(); pix_seed.release(); stats.release();
         scratch_f.release(); scratch_u.release();
         if (stream) (void)hipStreamDestroy(stream);
@@ -258,6 +339,7 @@ int ensure_workspace(rgk_scene* s, size_t paths) {
     if (!rc) rc = s->shA.alloc(paths);
     if (!rc) rc = s->shB.alloc(paths);
     if (!rc) rc = s->shC.alloc(paths);
+    if (!rc) rc = s->light.alloc(paths);
     if (!rc) rc = s->counters.alloc(RGK_CNT_TOTAL);
     if (!rc) rc = s->stats.alloc(8);
     if (rc) return rc;
@@ -454,8 +536,12 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
         for (uint32_t t : bb.order) leaf_recs.push_back(recs[t]);
         if (bb.order.size() >= (1u << 27)) return fail(RGK_ERR_UNSUPPORTED, "too many triangles for the leaf encoding");
     }
-    if (max_depth + 1 > 64) return fail(RGK_ERR_UNSUPPORTED, "BVH depth %u exceeds the 64-entry LDS stack", max_depth);
-    s->stack = (max_depth + 1 <= 32) ? 32 : 64;
+    QbvhBuilder qb(nodes);
+    qb.out.reserve(nodes.size() / 2 + 1);
+    if (qb.collapse(0, 0, 0) != 0) return fail(RGK_ERR_DEVICE, "internal: QBVH root is not node 0");
+    if (qb.max_stack + 1 > 64) return fail(RGK_ERR_UNSUPPORTED, "BVH needs %u traversal-stack entries (max 64)", qb.max_stack + 1);
+    s->stack = (qb.max_stack + 1 <= 32) ? 32 : 64;
+    max_depth = qb.max_depth;
 
     // ---- shading arrays
     std::vector<TriShade> tsh(nt);
@@ -530,7 +616,7 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
         al.count = (uint32_t)twa.size();
         for (auto& p : twa) {
             DevArealTri at{};
-            at.area = p.first; at.tri = p.second;
+            at.area = p.first; at.tri = p.second; at.light = (uint32_t)als.size();
             uint32_t ia = d->tri_indices[3 * p.second], ib = d->tri_indices[3 * p.second + 1], ic = d->tri_indices[3 * p.second + 2];
             for (int k = 0; k < 3; k++) {
                 at.a[k] = d->vertices[3 * ia + k]; at.b[k] = d->vertices[3 * ib + k]; at.c[k] = d->vertices[3 * ic + k];
@@ -546,7 +632,7 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
     build_halton(hd, hp);
 
     // ---- upload
-    if ((rc = s->nodes.upload(nodes)) || (rc = s->tris.upload(leaf_recs)) || (rc = s->tri_shade.upload(tsh)) ||
+    if ((rc = s->nodes.upload(qb.out)) || (rc = s->tris.upload(leaf_recs)) || (rc = s->tri_shade.upload(tsh)) ||
         (rc = s->vtx.upload(vtx)) || (rc = s->materials.upload(mats)) || (rc = s->textures.upload(texs)) ||
         (rc = s->texels.upload(pool)) || (rc = s->pointlights.upload(pls)) || (rc = s->areal.upload(als)) ||
         (rc = s->areal_tris.upload(ats)) || (rc = s->hdims.upload(hd)) || (rc = s->hperm.upload(hp)))
@@ -568,7 +654,7 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
     inf.epsilon = eps;
     for (int a = 0; a < 3; a++) { inf.bbox_min[a] = ds.bb_min[a]; inf.bbox_max[a] = ds.bb_max[a]; }
     inf.total_areal_power = total_areal; inf.total_point_power = total_point;
-    inf.n_nodes = (uint32_t)nodes.size(); inf.node_bytes = RGK_NODE_BYTES; inf.tri_bytes = RGK_TRI_BYTES;
+    inf.n_nodes = (uint32_t)qb.out.size(); inf.node_bytes = RGK_NODE_BYTES; inf.tri_bytes = RGK_TRI_BYTES;
     inf.max_depth = max_depth; inf.n_leaf_refs = (uint32_t)leaf_recs.size();
     guard.s = nullptr;
     *out = s;
@@ -696,6 +782,9 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
     pp.multisample = prm->multisample; pp.depth = prm->depth; pp.xres = prm->xres; pp.yres = prm->yres;
     pp.clamp = prm->clamp; pp.russian = prm->russian; pp.bumpmap_scale = prm->bumpmap_scale; pp.reverse = prm->reverse;
     pp.pix_xy = s->pix_xy.p; pp.pix_seed = s->pix_seed.p;
+    if ((rc = s->htab.alloc((size_t)192 * prm->multisample))) return rc;
+    TIMED(3, rgk_launch_build_halton_table(st, s->dev, prm->multisample, s->htab.p));
+    pp.htab = s->htab.p; pp.light = s->light.p;
     for (size_t j0 = 0; j0 < P; j0 += npix_pass) {
         pp.j0 = (uint32_t)j0;
         pp.npix = (uint32_t)std::min(npix_pass, P - j0);

@@ -4,7 +4,7 @@
 #include "device_types.h"
 
 #define RGK_TRACE_BLOCK 256
-#define RGK_SHADE_BLOCK 256
+#define RGK_SHADE_BLOCK 512
 #define RGK_MAX_DEPTH 62
 
 // device counter block (uint32), zeroed per pass by k_init_counters
@@ -23,9 +23,12 @@ struct PassParams {
     uint32_t reverse;
     const uint32_t* pix_xy;   // x | y << 16, per pixel of the round
     const uint32_t* pix_seed; // PathTracer::samplerSeed for that pixel (a2)
+    const float* htab;        // halton_raw(hdim, s) for hdim < 192, s < multisample: htab[hdim * multisample + s]
+    float4* light;            // per slot: the path's light {pos.xyz, code}, written by k_raygen
 };
 
 void rgk_launch_init_counters(hipStream_t st, uint32_t* counters, uint32_t n0);
+void rgk_launch_build_halton_table(hipStream_t st, const DevScene& sc, uint32_t S, float* htab);
 void rgk_launch_raygen(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, float4* rayA, float4* rayB,
                        float4* thr, float4* tot);
 void rgk_launch_trace_closest(hipStream_t st, const DevScene& sc, int stack, bool count_stats, const float4* rayA, const float4* rayB,

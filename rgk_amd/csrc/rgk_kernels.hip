@@ -8,204 +8,15 @@
 //
 // Design: one path per slot, SoA-of-float4 queues so every lane moves 16 B
 // per load; persistent waves pull 64 rays at a time from a device-side counter; a
-// per-lane traversal stack lives in LDS ([depth][lane] -> conflict-free); surviving
-// paths are compacted into the next bounce's queue with a wave ballot + prefix popcount
-// and one atomic per wave.  No MFMA: there is no dense contraction on this path.
+// per-lane traversal stack lives in LDS ([depth][lane] -> conflict-free) and idle lanes are
+// refilled with fresh rays (rgk_trace.h); surviving paths are compacted into the next
+// bounce's queue with a wave ballot + prefix popcount and one atomic per workgroup.
+// No MFMA: there is no dense contraction on this path.
 #include <hip/hip_runtime.h>
 #include "rgk_device.h"
 #include "rgk_kernels.h"
 
-#define STACK_SENTINEL 0x7fffffff
-
-// ------------------------------------------------------------------ triangle test (a8)
-// Triangle::TestIntersection, reference src/primitives.cpp:75-166.  r0..r2 = TriIsect.
-__device__ __forceinline__ bool tri_test(const float4 r0, const float4 r1, const float4 r2, const f3 o, const f3 d,
-                                         const float eps, float& t, float& alpha, float& beta) {
-    f3 n = mk3(r0.x, r0.y, r0.z);
-    double dotv = (double)dot3(d, n);
-    if (dotv != dotv) return false;
-    if (dotv < (double)eps && dotv > (double)(-eps)) return false;
-    double dot2 = (double)dot3(o, n);
-    t = (float)(-((double)r0.w + dot2) / dotv);
-    uint32_t axes = __float_as_uint(r2.z);
-    int i1 = axes & 3, i2 = (axes >> 2) & 3;
-    float px = comp(o, i1) + comp(d, i1) * t;
-    float py = comp(o, i2) + comp(d, i2) * t;
-    float q0x = px - r1.x, q0y = py - r1.y;
-    float q1x = r1.z, q1y = r1.w, q2x = r2.x, q2y = r2.y;
-    if (q1x > -eps && q1x < eps) {
-        beta = q0x / q2x;
-        if (beta < 0 || beta > 1) return false;
-        alpha = (q0y - beta * q2y) / q1y;
-    } else {
-        beta = (q0y * q1x - q0x * q1y) / (q2y * q1x - q2x * q1y);
-        if (beta < 0 || beta > 1) return false;
-        alpha = (q0x - beta * q2x) / q1x;
-    }
-    if (alpha < 0 || (double)(alpha + beta) > 1.0) return false;
-    return true;
-}
-
-// Scene-bbox clip of [near, far], reference src/scene_intersect.cpp:223-232
-__device__ __forceinline__ bool clip_to_scene(const DevScene& sc, f3 o, f3 d, float tnear, float tfar, float& t0, float& t1) {
-    t0 = tnear; t1 = tfar;
-    for (int i = 0; i < 3; ++i) {
-        float invRayDir = 1.f / comp(d, i);
-        float tN = (sc.bb_min[i] - comp(o, i)) * invRayDir;
-        float tF = (sc.bb_max[i] - comp(o, i)) * invRayDir;
-        if (tN > tF) { float s = tN; tN = tF; tF = s; }
-        t0 = tN > t0 ? tN : t0;
-        t1 = tF < t1 ? tF : t1;
-        if (t0 > t1) return false;
-    }
-    return true;
-}
-
-// Slab test of one child box against [tlo, thi]; NaNs (0*inf) drop out of fmin/fmax, which
-// only ever widens the interval (conservative).
-__device__ __forceinline__ bool box_test(float bx0, float by0, float bz0, float bx1, float by1, float bz1, f3 o, f3 inv,
-                                         float tlo, float thi, float& tentry) {
-    float tx0 = (bx0 - o.x) * inv.x, tx1 = (bx1 - o.x) * inv.x;
-    float ty0 = (by0 - o.y) * inv.y, ty1 = (by1 - o.y) * inv.y;
-    float tz0 = (bz0 - o.z) * inv.z, tz1 = (bz1 - o.z) * inv.z;
-    float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tlo));
-    float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), thi));
-    tentry = tn;
-    return tn <= tf;
-}
-
-// One ray through the BVH.  Result semantics = the reference's kd traversal: nearest
-// accepted hit with t in [t0 - eps, t1 + eps] (t0,t1 = the ray's range clipped to the
-// padded scene box), first-tested wins exact ties, `ignore` skipped.  ANY: stop at the
-// first accepted hit (Scene::Visibility only asks whether .triangle is set).
-template <bool ANY, bool COUNT, int STACK>
-__device__ __forceinline__ void traverse(const DevScene& sc, int* __restrict__ stack /* [STACK][blockDim] + tid */, const int stride,
-                                         f3 o, f3 d, float tnear, float tfar, uint32_t ignore, float& best_t, float& best_a,
-                                         float& best_b, int& best_tri, uint32_t& n_nodes, uint32_t& n_tris) {
-    best_t = __builtin_inff();
-    best_tri = -1;
-    best_a = 0.f; best_b = 0.f;
-    float t0, t1;
-    if (!clip_to_scene(sc, o, d, tnear, tfar, t0, t1)) return;
-    const float eps = sc.epsilon;
-    const float tlo = t0 - eps, thi = t1 + eps;
-    f3 inv = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
-    const float4* __restrict__ nodes = reinterpret_cast<const float4*>(sc.nodes);
-    const float4* __restrict__ tris = reinterpret_cast<const float4*>(sc.tris);
-    int sp = 0;
-    int cur = 0;
-    for (;;) {
-        while (cur >= 0 && cur != STACK_SENTINEL) {
-            const float4 n0 = nodes[4 * cur + 0], n1 = nodes[4 * cur + 1], n2 = nodes[4 * cur + 2], n3 = nodes[4 * cur + 3];
-            if (COUNT) n_nodes++;
-            float limit = ANY ? thi : fminf(thi, best_t);
-            float tl, tr;
-            bool hl = box_test(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, o, inv, tlo, limit, tl);
-            bool hr = box_test(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, o, inv, tlo, limit, tr);
-            int cl = __float_as_int(n3.x), cr = __float_as_int(n3.y);
-            if (hl && hr) {
-                bool lfirst = tl <= tr;
-                int nearc = lfirst ? cl : cr, farc = lfirst ? cr : cl;
-                if (sp < STACK) { stack[sp * stride] = farc; sp++; }
-                cur = nearc;
-            } else if (hl) cur = cl;
-            else if (hr) cur = cr;
-            else {
-                if (sp == 0) { cur = STACK_SENTINEL; break; }
-                sp--; cur = stack[sp * stride];
-            }
-        }
-        if (cur == STACK_SENTINEL) break;
-        // leaf
-        uint32_t code = ~(uint32_t)cur;
-        uint32_t first = code >> 4, cnt = (code & 15u) + 1u;
-        for (uint32_t k = 0; k < cnt; k++) {
-            const float4 r0 = tris[3 * (first + k) + 0], r1 = tris[3 * (first + k) + 1], r2 = tris[3 * (first + k) + 2];
-            uint32_t tid = __float_as_uint(r2.w);
-            if (tid == ignore) continue;
-            if (COUNT) n_tris++;
-            float t, al, be;
-            if (tri_test(r0, r1, r2, o, d, eps, t, al, be)) {
-                if (t < tlo || t > thi) continue;
-                if (t < best_t) { best_t = t; best_tri = (int)tid; best_a = al; best_b = be; if (ANY) return; }
-            }
-        }
-        if (sp == 0) break;
-        sp--; cur = stack[sp * stride];
-    }
-}
-
-// ------------------------------------------------------------------ K2: closest hit
-template <bool COUNT, int STACK>
-__global__ __launch_bounds__(RGK_TRACE_BLOCK) void k_trace_closest(const DevScene sc, const float4* __restrict__ rayA,
-                                                                    const float4* __restrict__ rayB, const float2* __restrict__ nearfar,
-                                                                    float4* __restrict__ hit, const uint32_t* __restrict__ count_ptr,
-                                                                    uint32_t* __restrict__ fetch, unsigned long long* __restrict__ stats) {
-    __shared__ int lds_stack[STACK * RGK_TRACE_BLOCK];
-    int* stack = lds_stack + threadIdx.x;
-    const uint32_t count = *count_ptr;
-    const int lane = threadIdx.x & 63;
-    uint32_t n_nodes = 0, n_tris = 0;
-    for (;;) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(fetch, 64u);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (base >= count) break;
-        uint32_t i = base + lane;
-        if (i < count) {
-            const float4 a = rayA[i], b = rayB[i];
-            f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
-            float tn = 0.0f, tf = 10000.0f; // Ray::near / Ray::far defaults, reference src/ray.hpp:25-26
-            if (nearfar) { float2 nf = nearfar[i]; tn = nf.x; tf = nf.y; }
-            float bt, ba, bb; int btri;
-            traverse<false, COUNT, STACK>(sc, stack, RGK_TRACE_BLOCK, o, d, tn, tf, __float_as_uint(b.z), bt, ba, bb, btri, n_nodes, n_tris);
-            hit[i] = make_float4(bt, ba, bb, __int_as_float(btri));
-        }
-    }
-    if (COUNT) {
-        atomicAdd(&stats[0], (unsigned long long)n_nodes);
-        atomicAdd(&stats[1], (unsigned long long)n_tris);
-    }
-}
-
-// ------------------------------------------------------------------ K5: shadow rays + accumulate
-// shA = (o.xyz, d.x)  shB = (d.y, d.z, far, slot)  shC = (radiance.rgb, near)
-template <bool COUNT, int STACK>
-__global__ __launch_bounds__(RGK_TRACE_BLOCK) void k_trace_shadow(const DevScene sc, const float4* __restrict__ shA,
-                                                                   const float4* __restrict__ shB, const float4* __restrict__ shC,
-                                                                   float4* __restrict__ tot, uint8_t* __restrict__ vis_out,
-                                                                   const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ fetch,
-                                                                   unsigned long long* __restrict__ stats) {
-    __shared__ int lds_stack[STACK * RGK_TRACE_BLOCK];
-    int* stack = lds_stack + threadIdx.x;
-    const uint32_t count = *count_ptr;
-    const int lane = threadIdx.x & 63;
-    uint32_t n_nodes = 0, n_tris = 0;
-    for (;;) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(fetch, 64u);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (base >= count) break;
-        uint32_t i = base + lane;
-        if (i < count) {
-            const float4 a = shA[i], b = shB[i], c = shC[i];
-            f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
-            float bt, ba, bb; int btri;
-            traverse<true, COUNT, STACK>(sc, stack, RGK_TRACE_BLOCK, o, d, c.w, b.z, 0xffffffffu, bt, ba, bb, btri, n_nodes, n_tris);
-            if (vis_out) vis_out[i] = btri < 0;
-            else if (btri < 0) {
-                uint32_t slot = __float_as_uint(b.w);
-                float4 t = tot[slot]; // one path per slot, one shadow ray per path and bounce: no race
-                t.x = t.x + c.x; t.y = t.y + c.y; t.z = t.z + c.z;
-                tot[slot] = t;
-            }
-        }
-    }
-    if (COUNT) {
-        atomicAdd(&stats[2], (unsigned long long)n_nodes);
-        atomicAdd(&stats[3], (unsigned long long)n_tris);
-    }
-}
+#include "rgk_trace.h" // K2 / K5: persistent traversal with lane refill
 
 // ------------------------------------------------------------------ K1: ray generation
 // Camera::GetPixelRay / GetPixelRayLens, reference src/camera.cpp:26-46; Ray ctor src/ray.hpp:10-13
@@ -231,11 +42,18 @@ __global__ __launch_bounds__(256) void k_raygen(const DevScene sc, const DevCame
         uint32_t srel = slot / pp.npix, j = slot - srel * pp.npix;
         uint32_t pix = pp.pix_xy[pp.j0 + j], seed = pp.pix_seed[pp.j0 + j];
         uint32_t s = pp.s0 + srel;
-        float2 jit = sample2d(sc, seed, s, 0);
+        const SamplerTab tb = {pp.htab, pp.multisample};
+        float2 jit = sample2d_t(tb, seed, s, 0);
         float2 lens = make_float2(0.f, 0.f);
-        if (cam.lens_size != 0.0f) lens = sample2d(sc, seed, s, 1);
+        uint32_t base2d = 1u;
+        if (cam.lens_size != 0.0f) { lens = sample2d_t(tb, seed, s, 1); base2d = 2u; }
         f3 o, d;
         camera_ray(cam, (int)(pix & 0xffff), (int)(pix >> 16), (int)pp.xres, (int)pp.yres, jit, lens, o, d);
+        // TracePath: areal_sample, (lightdir_sample), GetRandomLight(Get2D, Get1D, areal_sample) -- path_tracer.cpp:315-322
+        f3 lpos;
+        uint32_t lcode = light_code(sc, sample2d_t(tb, seed, s, base2d + 2u), sample1d_t(tb, seed, s, 0u),
+                                    sample2d_t(tb, seed, s, base2d), lpos);
+        pp.light[slot] = make_float4(lpos.x, lpos.y, lpos.z, __uint_as_float(lcode));
         rayA[slot] = make_float4(o.x, o.y, o.z, d.x);
         rayB[slot] = make_float4(d.y, d.z, __uint_as_float(0xffffffffu), __uint_as_float(slot));
         thr[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(1u << 16)); // n = 0, 1-D counter = 1
@@ -246,18 +64,20 @@ __global__ __launch_bounds__(256) void k_raygen(const DevScene sc, const DevCame
 // ------------------------------------------------------------------ K3+K4+K6+K7: shade
 __device__ __forceinline__ f3 clamp3(f3 v, float c) { return mk3(v.x > c ? c : v.x, v.y > c ? c : v.y, v.z > c ? c : v.z); }
 
-__global__ __launch_bounds__(RGK_SHADE_BLOCK) void k_shade(const DevScene sc, const DevCamera cam, const PassParams pp, const uint32_t bounce,
+__global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade(const DevScene sc, const DevCamera cam, const PassParams pp, const uint32_t bounce,
                                                             const float4* __restrict__ rayA, const float4* __restrict__ rayB,
                                                             const float4* __restrict__ hit, float4* __restrict__ thr, float4* __restrict__ tot,
                                                             float4* __restrict__ nextA, float4* __restrict__ nextB, float4* __restrict__ shA,
                                                             float4* __restrict__ shB, float4* __restrict__ shC, uint32_t* __restrict__ counters) {
     const uint32_t count = counters[RGK_CNT_QUEUE + bounce];
     const int lane = threadIdx.x & 63;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const float eps = sc.epsilon;
-    for (uint32_t base = wave * 64; base < count; base += nwaves * 64) {
-        const uint32_t i = base + lane;
+    const SamplerTab tb = {pp.htab, pp.multisample};
+    __shared__ uint32_t s_cnt[2][RGK_SHADE_BLOCK / 64];
+    __shared__ uint32_t s_base[2];
+    // workgroup-uniform trip count (the compaction below synchronises the workgroup)
+    for (uint32_t base = blockIdx.x * RGK_SHADE_BLOCK; base < count; base += gridDim.x * RGK_SHADE_BLOCK) {
+        const uint32_t i = base + threadIdx.x;
         const bool valid = i < count;
         bool cont = false, shadow = false;
         float4 nA = make_float4(0, 0, 0, 0), nB = nA, sA = nA, sB = nA, sC = nA;
@@ -326,9 +146,11 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK) void k_shade(const DevScene sc, co
                     const quatf l2g = qinverse(g2l);
                     const f3 VrL = qrot(g2l, Vr);
                     // BxDF sample, path_tracer.cpp:243-250
-                    float2 u = sample2d(sc, seed, s, base2d + 3u + (n - 1u));
+                    float2 u = sample2d_t(tb, seed, s, base2d + 3u + (n - 1u));
                     f3 dirL, weight; bool may_leak;
-                    bxdf_sample(sc, (int)ts.mat, VrL, uv, u, dirL, weight, may_leak);
+                    MatPrep mp;
+                    mat_prepare(sc, mat, uv, VrL, mp);
+                    mat_sample(sc, (int)ts.mat, mat, mp, VrL, uv, u, dirL, weight, may_leak);
                     const bool inside = dirL.z < 0;
                     f3 dir = qrot(l2g, dirL);
                     uint32_t n_eff = n;
@@ -341,11 +163,8 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK) void k_shade(const DevScene sc, co
 
                     // ---- phase 3 for this vertex: NEE to the path's light, :427-460,485-496
                     {
-                        const float2 areal_s = sample2d(sc, seed, s, base2d);
-                        const float2 choice_s = sample2d(sc, seed, s, base2d + 2u);
-                        const float pick = sample1d(sc, seed, s, 0u);
-                        DLight L = random_light(sc, choice_s, pick, areal_s);
-                        if (L.type == 0) L.pos = L.pos + L.size * sphere_uniform(areal_s); // :339-342
+                        const float4 li = pp.light[slot];
+                        const DLight L = light_from_code(sc, mk3(li.x, li.y, li.z), __float_as_uint(li.w));
                         f3 e_front = mk3(0.f, 0.f, 0.f);
                         if (dot3(faceN, Vr) > 0) e_front = mk3(mat.emission[0], mat.emission[1], mat.emission[2]);
                         const bool has_e = (e_front.x != 0.f) || (e_front.y != 0.f) || (e_front.z != 0.f);
@@ -361,7 +180,7 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK) void k_shade(const DevScene sc, co
                             const f3 sd = norm3(diff);
                             const float slen = len3(diff);
                             const f3 Vi = norm3(L.pos - pos);
-                            const f3 f = bxdf_value(sc, (int)ts.mat, qrot(g2l, Vi), VrL, uv);
+                            const f3 f = mat_value(sc, (int)ts.mat, mat, mp, qrot(g2l, Vi), VrL, uv);
                             const float G = fabsf(dot3(lightN, Vi)) / dot3(diff, diff);
                             const float k = L.intensity * light_dir_factor(L, -Vi);
                             const f3 inc = L.color * mk3(k, k, k);
@@ -379,7 +198,7 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK) void k_shade(const DevScene sc, co
                     // ---- continuation, path_tracer.cpp:275-300
                     bool go = !(max3c(cum) < 0.001f);
                     if (go && !no_russian && pp.russian >= 0.0f) {
-                        float r = sample1d(sc, seed, s, c1);
+                        float r = sample1d_t(tb, seed, s, c1);
                         c1++;
                         if (r > pp.russian) go = false;
                     }
@@ -397,28 +216,30 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK) void k_shade(const DevScene sc, co
                 }
             }
         }
-        // ---- K7: wave-level compaction into the next queues
+        // ---- K7: compaction into the next queues.  Wave ballot + prefix popcount inside the wave,
+        // the waves of the workgroup add up through LDS, and ONE atomic per workgroup and queue
+        // reserves the range (a single counter word only sustains ~88 returning atomics/us chip-wide).
         {
-            unsigned long long m = __ballot(cont);
-            if (m) {
-                uint32_t total = __popcll(m), off = 0;
-                if (lane == 0) off = atomicAdd(&counters[RGK_CNT_QUEUE + bounce + 1], total);
-                off = __builtin_amdgcn_readfirstlane(off);
-                if (cont) {
-                    uint32_t p = off + __popcll(m & ((1ull << lane) - 1ull));
-                    nextA[p] = nA; nextB[p] = nB;
-                }
+            const unsigned long long m = __ballot(cont), ms = __ballot(shadow);
+            const int w = threadIdx.x >> 6;
+            if (lane == 0) { s_cnt[0][w] = __popcll(m); s_cnt[1][w] = __popcll(ms); }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t t0 = 0, t1 = 0;
+                for (int k = 0; k < RGK_SHADE_BLOCK / 64; k++) { uint32_t a = s_cnt[0][k], b = s_cnt[1][k]; s_cnt[0][k] = t0; s_cnt[1][k] = t1; t0 += a; t1 += b; }
+                s_base[0] = t0 ? atomicAdd(&counters[RGK_CNT_QUEUE + bounce + 1], t0) : 0u;
+                s_base[1] = t1 ? atomicAdd(&counters[RGK_CNT_SHADOW + bounce], t1) : 0u;
             }
-            unsigned long long ms = __ballot(shadow);
-            if (ms) {
-                uint32_t total = __popcll(ms), off = 0;
-                if (lane == 0) off = atomicAdd(&counters[RGK_CNT_SHADOW + bounce], total);
-                off = __builtin_amdgcn_readfirstlane(off);
-                if (shadow) {
-                    uint32_t p = off + __popcll(ms & ((1ull << lane) - 1ull));
-                    shA[p] = sA; shB[p] = sB; shC[p] = sC;
-                }
+            __syncthreads();
+            if (cont) {
+                uint32_t p = s_base[0] + s_cnt[0][w] + __popcll(m & ((1ull << lane) - 1ull));
+                nextA[p] = nA; nextB[p] = nB;
             }
+            if (shadow) {
+                uint32_t p = s_base[1] + s_cnt[1][w] + __popcll(ms & ((1ull << lane) - 1ull));
+                shA[p] = sA; shB[p] = sB; shC[p] = sC;
+            }
+            __syncthreads(); // s_cnt / s_base are rewritten by the next iteration
         }
     }
 }
@@ -448,6 +269,15 @@ __global__ __launch_bounds__(256) void k_resolve(const PassParams pp, const floa
         } else {
             pixsum[pp.j0 + j] = acc;
         }
+    }
+}
+
+// halton_raw tabulated once per round: htab[hdim * S + s]
+__global__ void k_build_halton_table(const DevScene sc, uint32_t S, float* __restrict__ htab) {
+    const uint32_t n = 192u * S;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        uint32_t hdim = i / S, s = i - hdim * S;
+        htab[i] = halton_raw(sc, hdim, s);
     }
 }
 
@@ -503,6 +333,10 @@ static inline int trace_grid(int stack) {
 }
 
 void rgk_launch_init_counters(hipStream_t st, uint32_t* counters, uint32_t n0) { k_init_counters<<<1, 256, 0, st>>>(counters, n0); }
+void rgk_launch_build_halton_table(hipStream_t st, const DevScene& sc, uint32_t S, float* htab) {
+    uint32_t n = 192u * S;
+    k_build_halton_table<<<(n + 255) / 256, 256, 0, st>>>(sc, S, htab);
+}
 
 void rgk_launch_raygen(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, float4* rayA, float4* rayB, float4* thr, float4* tot) {
     uint32_t n = pp.npix * pp.ns;
@@ -533,7 +367,7 @@ void rgk_launch_trace_shadow(hipStream_t st, const DevScene& sc, int stack, bool
 void rgk_launch_shade(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t bounce, const float4* rayA,
                       const float4* rayB, const float4* hit, float4* thr, float4* tot, float4* nextA, float4* nextB, float4* shA,
                       float4* shB, float4* shC, uint32_t* counters) {
-    k_shade<<<256 * 8, RGK_SHADE_BLOCK, 0, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
+    k_shade<<<256 * 4, RGK_SHADE_BLOCK, 0, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
 }
 
 void rgk_launch_resolve(hipStream_t st, const PassParams& pp, const float4* tot, float4* pixsum, float* accum_rgb, uint32_t* accum_count) {

@@ -1,0 +1,279 @@
+// Ray traversal kernels (K2 closest hit, K5 shadow / visibility) for gfx950.
+//
+// Result semantics are the reference's kd traversal (src/scene_intersect.cpp:4-116,211-327):
+// nearest accepted hit with t in [t0 - eps, t1 + eps] where [t0, t1] is the ray's [near, far]
+// clipped to the epsilon-padded scene box (:223-232,272), first-tested wins exact ties, the
+// `ignore` triangle is skipped; the triangle test is Triangle::TestIntersection
+// (src/primitives.cpp:75-166) with its fp64 plane solve.  The accelerator is the build's own:
+// a 4-wide BVH with 8-bit quantised child boxes, one 64-byte line per node (device_types.h).
+//
+// Execution model: persistent waves with per-lane ray REFILL.  Round-1 counters showed the
+// kernel is VALU-issue bound (SQ_ACTIVE_INST_ANY ~= all SIMD cycles) at ~1/3 lane utilisation:
+// rays of one 64-ray batch finish at very different times.  So a wave keeps a cursor into its
+// chunk of the ray queue and, whenever a quarter of its lanes are idle, hands them fresh rays
+// (ballot + prefix popcount); a lane that drains its stack stores its hit and goes idle.
+// The per-lane traversal stack lives in LDS as [entry][lane] (bank = lane: conflict-free).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "rgk_device.h"
+#include "rgk_kernels.h"
+
+#define STACK_SENTINEL 0x7fffffff
+#define RGK_REFILL_BELOW 48 // refill a wave when at most this many lanes still hold a ray
+
+// Triangle::TestIntersection, reference src/primitives.cpp:75-166.  r0..r2 = TriIsect.
+__device__ __forceinline__ bool tri_test(const float4 r0, const float4 r1, const float4 r2, const f3 o, const f3 d,
+                                         const float eps, float& t, float& alpha, float& beta) {
+    f3 n = mk3(r0.x, r0.y, r0.z);
+    double dotv = (double)dot3(d, n);
+    if (dotv != dotv) return false;
+    if (dotv < (double)eps && dotv > (double)(-eps)) return false;
+    double dot2 = (double)dot3(o, n);
+    t = (float)(-((double)r0.w + dot2) / dotv);
+    uint32_t axes = __float_as_uint(r2.z);
+    int i1 = axes & 3, i2 = (axes >> 2) & 3;
+    float px = comp(o, i1) + comp(d, i1) * t;
+    float py = comp(o, i2) + comp(d, i2) * t;
+    float q0x = px - r1.x, q0y = py - r1.y;
+    float q1x = r1.z, q1y = r1.w, q2x = r2.x, q2y = r2.y;
+    if (q1x > -eps && q1x < eps) {
+        beta = q0x / q2x;
+        if (beta < 0 || beta > 1) return false;
+        alpha = (q0y - beta * q2y) / q1y;
+    } else {
+        beta = (q0y * q1x - q0x * q1y) / (q2y * q1x - q2x * q1y);
+        if (beta < 0 || beta > 1) return false;
+        alpha = (q0x - beta * q2x) / q1x;
+    }
+    if (alpha < 0 || (double)(alpha + beta) > 1.0) return false;
+    return true;
+}
+
+// Scene-bbox clip of [near, far], reference src/scene_intersect.cpp:223-232
+__device__ __forceinline__ bool clip_to_scene(const DevScene& sc, f3 o, f3 d, float tnear, float tfar, float& t0, float& t1) {
+    t0 = tnear; t1 = tfar;
+    for (int i = 0; i < 3; ++i) {
+        float invRayDir = 1.f / comp(d, i);
+        float tN = (sc.bb_min[i] - comp(o, i)) * invRayDir;
+        float tF = (sc.bb_max[i] - comp(o, i)) * invRayDir;
+        if (tN > tF) { float s = tN; tN = tF; tF = s; }
+        t0 = tN > t0 ? tN : t0;
+        t1 = tF < t1 ? tF : t1;
+        if (t0 > t1) return false;
+    }
+    return true;
+}
+
+// A wave takes `chunk` consecutive rays per visit to the device-wide cursor.  One returning atomic
+// on a single word sustains only ~88 dequeues/us chip-wide (MI355X guide, price list "dequeue"):
+// at 64 rays per dequeue that alone capped the kernel at ~5.6 G rays/s, so the chunk grows with
+// the queue.
+__device__ __forceinline__ uint32_t fetch_chunk(uint32_t count, uint32_t nwaves) {
+    uint32_t c = (count / (nwaves * 4u)) & ~63u;
+    return c < 64u ? 64u : (c > 2048u ? 2048u : c);
+}
+
+__device__ __forceinline__ float cvt_ubyte(uint32_t w, int c) { return (float)((w >> (8 * c)) & 0xffu); }
+
+// ANY = false: closest hit, results to hit[i] = {t, alpha, beta, tri}.
+// ANY = true : Scene::Visibility; vis_out[i] = visible, or (path mode) tot[slot] += radiance if visible.
+//   q0 = {o.xyz, d.x}; q1 = {d.y, d.z, ignore | far, slot}; q2 = {radiance.rgb, near} (shadow only)
+template <bool ANY, bool COUNT, int STACK>
+__device__ __forceinline__ void trace_persistent(const DevScene& sc, const float4* __restrict__ q0, const float4* __restrict__ q1,
+                                                 const float4* __restrict__ q2, const float2* __restrict__ nearfar,
+                                                 float4* __restrict__ hit, float4* __restrict__ tot, uint8_t* __restrict__ vis_out,
+                                                 const uint32_t count, uint32_t* __restrict__ fetch, int* __restrict__ stack,
+                                                 uint32_t& n_nodes, uint32_t& n_tris) {
+    const int lane = threadIdx.x & 63;
+    const int stride = RGK_TRACE_BLOCK;
+    const float eps = sc.epsilon;
+    const float4* __restrict__ nodes = reinterpret_cast<const float4*>(sc.nodes);
+    const float4* __restrict__ tris = reinterpret_cast<const float4*>(sc.tris);
+    const uint32_t chunk = fetch_chunk(count, gridDim.x * (RGK_TRACE_BLOCK / 64));
+    uint32_t w_next = 0, w_end = 0; // wave-uniform: this wave's slice of the queue
+    bool exhausted = false;         // wave-uniform: the device cursor has passed `count`
+    // per-lane ray state
+    bool active = false;
+    uint32_t idx = 0, ignore = 0xffffffffu, slot = 0;
+    f3 o = mk3(0.f, 0.f, 0.f), d = o, inv = o, rad = o;
+    float tlo = 0.f, thi = 0.f, best_t = 0.f, best_a = 0.f, best_b = 0.f;
+    int best_tri = -1, cur = STACK_SENTINEL, sp = 0;
+
+    for (;;) {
+        // ------------------------------------------------ refill idle lanes
+        unsigned long long act = __ballot(active);
+        const int nact = __popcll(act);
+        if (nact <= RGK_REFILL_BELOW && !(exhausted && w_next >= w_end)) {
+            if (w_next >= w_end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(fetch, chunk);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= count) exhausted = true;
+                else { w_next = base; w_end = min(base + chunk, count); }
+            }
+            const uint32_t avail = (w_end > w_next) ? (w_end - w_next) : 0u;
+            if (avail) {
+                const unsigned long long idle = ~act;
+                const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
+                if (!active && rank < avail) {
+                    idx = w_next + rank;
+                    const float4 a = q0[idx], b = q1[idx];
+                    o = mk3(a.x, a.y, a.z); d = mk3(a.w, b.x, b.y);
+                    float tn = 0.0f, tf = 10000.0f; // Ray::near / Ray::far defaults, src/ray.hpp:25-26
+                    if (ANY) {
+                        const float4 c = q2[idx];
+                        rad = mk3(c.x, c.y, c.z); tn = c.w; tf = b.z;
+                        slot = __float_as_uint(b.w);
+                        ignore = 0xffffffffu;
+                    } else {
+                        ignore = __float_as_uint(b.z);
+                        if (nearfar) { float2 nf = nearfar[idx]; tn = nf.x; tf = nf.y; }
+                    }
+                    best_t = __builtin_inff(); best_tri = -1; best_a = 0.f; best_b = 0.f;
+                    float t0, t1;
+                    sp = 0;
+                    if (clip_to_scene(sc, o, d, tn, tf, t0, t1)) {
+                        tlo = t0 - eps; thi = t1 + eps;
+                        inv = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+                        cur = 0;
+                    } else cur = STACK_SENTINEL; // misses the scene box: reported below as a miss
+                    active = true;
+                }
+                const uint32_t taken = min(avail, (uint32_t)(64 - nact));
+                w_next += taken;
+            }
+            act = __ballot(active);
+        }
+        if (act == 0) {
+            if (exhausted && w_next >= w_end) break;
+            continue;
+        }
+        // ------------------------------------------------ inner nodes: until this lane reaches a leaf or runs dry
+        while (active && cur >= 0 && cur != STACK_SENTINEL) {
+            // one 64-byte QNode: {p.xyz, exps} {child[4]} {qlo.x qlo.y qlo.z qhi.x} {qhi.y qhi.z - -}
+            const float4 n0 = nodes[4 * cur + 0], n1 = nodes[4 * cur + 1], n2 = nodes[4 * cur + 2], n3 = nodes[4 * cur + 3];
+            if (COUNT) n_nodes++;
+            const float limit = ANY ? thi : fminf(thi, best_t);
+            const uint32_t ex = __float_as_uint(n0.w);
+            const float sx = __uint_as_float((ex & 0xffu) << 23), sy = __uint_as_float(((ex >> 8) & 0xffu) << 23),
+                        sz = __uint_as_float(((ex >> 16) & 0xffu) << 23);
+            // plane distance along the ray: t = (p + q*s - o) / d = q * (s/d) + (p - o)/d, one fma per plane.
+            // The split loses a few ulps of |(p-o)/d| to cancellation; the child boxes carry an absolute
+            // pad of eps = 1e-5 * scene diagonal, two orders above float resolution at scene scale, so the
+            // test stays conservative.  (Box tests only steer the walk: they never produce a result.)
+            const float kx = sx * inv.x, ky = sy * inv.y, kz = sz * inv.z;
+            const float cx = (n0.x - o.x) * inv.x, cy = (n0.y - o.y) * inv.y, cz = (n0.z - o.z) * inv.z;
+            // near / far plane words by the sign of 1/d: no per-plane min/max needed; an unused slot
+            // (qlo = 255, qhi = 0) then has near > far on every axis and can never be entered
+            const bool ngx = (__float_as_uint(inv.x) >> 31) != 0, ngy = (__float_as_uint(inv.y) >> 31) != 0, ngz = (__float_as_uint(inv.z) >> 31) != 0;
+            const uint32_t lx = __float_as_uint(n2.x), ly = __float_as_uint(n2.y), lz = __float_as_uint(n2.z);
+            const uint32_t hx = __float_as_uint(n2.w), hy = __float_as_uint(n3.x), hz = __float_as_uint(n3.y);
+            const uint32_t nx = ngx ? hx : lx, fx = ngx ? lx : hx;
+            const uint32_t ny = ngy ? hy : ly, fy = ngy ? ly : hy;
+            const uint32_t nz = ngz ? hz : lz, fz = ngz ? lz : hz;
+            float te[4];
+            int ref[4];
+            ref[0] = __float_as_int(n1.x); ref[1] = __float_as_int(n1.y); ref[2] = __float_as_int(n1.z); ref[3] = __float_as_int(n1.w);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                // NaNs (0 * inf on an axis-parallel ray) drop out of fmax/fmin, which only widens the
+                // interval (conservative).
+                const float t0x = __builtin_fmaf(cvt_ubyte(nx, c), kx, cx), t1x = __builtin_fmaf(cvt_ubyte(fx, c), kx, cx);
+                const float t0y = __builtin_fmaf(cvt_ubyte(ny, c), ky, cy), t1y = __builtin_fmaf(cvt_ubyte(fy, c), ky, cy);
+                const float t0z = __builtin_fmaf(cvt_ubyte(nz, c), kz, cz), t1z = __builtin_fmaf(cvt_ubyte(fz, c), kz, cz);
+                const float tn = fmaxf(fmaxf(fmaxf(t0x, t0y), t0z), tlo);
+                const float tf = fminf(fminf(fminf(t1x, t1y), t1z), limit);
+                const bool h = tn <= tf;
+                te[c] = h ? tn : __builtin_inff();
+                if (!h) ref[c] = STACK_SENTINEL;
+            }
+            if (!ANY) {
+                // sort the four (entry distance, ref) pairs ascending: 5-comparator network
+#define RGK_CSWAP(a, b) { const bool sw = te[b] < te[a]; const float tt = sw ? te[b] : te[a], tu = sw ? te[a] : te[b]; \
+                          const int rr = sw ? ref[b] : ref[a], ru = sw ? ref[a] : ref[b]; te[a] = tt; te[b] = tu; ref[a] = rr; ref[b] = ru; }
+                RGK_CSWAP(0, 1) RGK_CSWAP(2, 3) RGK_CSWAP(0, 2) RGK_CSWAP(1, 3) RGK_CSWAP(1, 2)
+#undef RGK_CSWAP
+                // misses carry te = inf / ref = SENTINEL and sort to the back; push far -> near
+                if (ref[3] != STACK_SENTINEL && sp < STACK) { stack[sp * stride] = ref[3]; sp++; }
+                if (ref[2] != STACK_SENTINEL && sp < STACK) { stack[sp * stride] = ref[2]; sp++; }
+                if (ref[1] != STACK_SENTINEL && sp < STACK) { stack[sp * stride] = ref[1]; sp++; }
+                cur = ref[0];
+            } else {
+                cur = STACK_SENTINEL; // any-hit: order is irrelevant; keep one hit child, push the rest
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    if (ref[c] != STACK_SENTINEL) {
+                        if (cur == STACK_SENTINEL) cur = ref[c];
+                        else if (sp < STACK) { stack[sp * stride] = ref[c]; sp++; }
+                    }
+                }
+            }
+            if (cur == STACK_SENTINEL && sp > 0) { sp--; cur = stack[sp * stride]; }
+        }
+        // ------------------------------------------------ leaf
+        if (active && cur < 0) {
+            const uint32_t code = ~(uint32_t)cur;
+            const uint32_t first = code >> 4, cnt = (code & 15u) + 1u;
+            bool done = false;
+            for (uint32_t k = 0; k < cnt && !done; k++) {
+                const float4 r0 = tris[3 * (first + k) + 0], r1 = tris[3 * (first + k) + 1], r2 = tris[3 * (first + k) + 2];
+                const uint32_t tid = __float_as_uint(r2.w);
+                if (tid == ignore) continue;
+                if (COUNT) n_tris++;
+                float t, al, be;
+                if (tri_test(r0, r1, r2, o, d, eps, t, al, be)) {
+                    if (t < tlo || t > thi) continue;
+                    if (t < best_t) { best_t = t; best_tri = (int)tid; best_a = al; best_b = be; if (ANY) done = true; }
+                }
+            }
+            if (ANY && done) { cur = STACK_SENTINEL; sp = 0; }
+            else if (sp > 0) { sp--; cur = stack[sp * stride]; }
+            else cur = STACK_SENTINEL;
+        }
+        // ------------------------------------------------ retire finished rays
+        if (active && cur == STACK_SENTINEL) {
+            if (!ANY) hit[idx] = make_float4(best_t, best_a, best_b, __int_as_float(best_tri));
+            else if (vis_out) vis_out[idx] = best_tri < 0;
+            else if (best_tri < 0) {
+                float4 t = tot[slot]; // one path per slot, one shadow ray per path and bounce: no race
+                t.x = t.x + rad.x; t.y = t.y + rad.y; t.z = t.z + rad.z;
+                tot[slot] = t;
+            }
+            active = false;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ K2: closest hit
+template <bool COUNT, int STACK>
+__global__ __launch_bounds__(RGK_TRACE_BLOCK) void k_trace_closest(const DevScene sc, const float4* __restrict__ rayA,
+                                                                    const float4* __restrict__ rayB, const float2* __restrict__ nearfar,
+                                                                    float4* __restrict__ hit, const uint32_t* __restrict__ count_ptr,
+                                                                    uint32_t* __restrict__ fetch, unsigned long long* __restrict__ stats) {
+    __shared__ int lds_stack[STACK * RGK_TRACE_BLOCK];
+    uint32_t n_nodes = 0, n_tris = 0;
+    trace_persistent<false, COUNT, STACK>(sc, rayA, rayB, nullptr, nearfar, hit, nullptr, nullptr, *count_ptr, fetch,
+                                          lds_stack + threadIdx.x, n_nodes, n_tris);
+    if (COUNT) {
+        atomicAdd(&stats[0], (unsigned long long)n_nodes);
+        atomicAdd(&stats[1], (unsigned long long)n_tris);
+    }
+}
+
+// ------------------------------------------------------------------ K5: shadow rays + accumulate
+// shA = (o.xyz, d.x)  shB = (d.y, d.z, far, slot)  shC = (radiance.rgb, near)
+template <bool COUNT, int STACK>
+__global__ __launch_bounds__(RGK_TRACE_BLOCK) void k_trace_shadow(const DevScene sc, const float4* __restrict__ shA,
+                                                                   const float4* __restrict__ shB, const float4* __restrict__ shC,
+                                                                   float4* __restrict__ tot, uint8_t* __restrict__ vis_out,
+                                                                   const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ fetch,
+                                                                   unsigned long long* __restrict__ stats) {
+    __shared__ int lds_stack[STACK * RGK_TRACE_BLOCK];
+    uint32_t n_nodes = 0, n_tris = 0;
+    trace_persistent<true, COUNT, STACK>(sc, shA, shB, shC, nullptr, nullptr, tot, vis_out, *count_ptr, fetch,
+                                         lds_stack + threadIdx.x, n_nodes, n_tris);
+    if (COUNT) {
+        atomicAdd(&stats[2], (unsigned long long)n_nodes);
+        atomicAdd(&stats[3], (unsigned long long)n_tris);
+    }
+}
