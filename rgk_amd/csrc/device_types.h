@@ -4,6 +4,7 @@
 // of SURVEY 8(d)).
 #pragma once
 #include <stdint.h>
+#include <hip/hip_runtime.h>
 #include "../../include/rgk.h"
 
 #define RGK_NODE_BYTES 64 // QNode
@@ -19,8 +20,8 @@ struct BvhNode {
 };
 
 // The node the kernels traverse: a 4-wide BVH node in ONE 64-byte line (4 dwordx4 per lane).
-// Child boxes are 8-bit offsets from the node's own box minimum `p`, in units of 2^(e-127) per
-// axis: lo = p + qlo * scale, hi = p + qhi * scale, rounded outward at build time, so a decoded
+// Child boxes are 8-bit offsets from the node's own box minimum `p`, in units of a per-axis
+// power-of-two step: lo = p + qlo * s, hi = p + qhi * s, rounded outward at build time, so a decoded
 // box always contains the (epsilon-padded) child box it stands for.  Box tests only steer the walk;
 // results come from the triangle records, so the quantisation cannot change a hit.
 // child[i] >= 0: inner node index; < 0: leaf, ~child = (first << 4) | (count - 1);
@@ -28,11 +29,11 @@ struct BvhNode {
 #define RGK_QNODE_EMPTY 0x7fffffff
 struct QNode {
     float p[3];
-    uint8_t e[3], pad0;
+    float sx;          // quantisation step of axis x (a power of two); sy, sz at the end of the line
     int32_t child[4];
     uint8_t qlo[3][4]; // [axis][child]
     uint8_t qhi[3][4];
-    uint32_t pad1[2];
+    float sy, sz;
 };
 
 // Everything Triangle::TestIntersection (reference src/primitives.cpp:75-166) reads for
@@ -47,30 +48,31 @@ struct TriIsect {
     uint32_t tri;        // original triangle index
 };
 
-// Per-vertex shading attributes: {normal.xyz, u}, {tangent.xyz, v}
-struct VtxAttr {
-    float nx, ny, nz, u;
-    float tx, ty, tz, v;
-};
-
+// Everything shading needs about one triangle, gathered behind ONE index (the hit's triangle id):
+// 7 x 16 B, contiguous -- instead of an index record followed by six scattered vertex fetches.
+//   {nA.xyz, uvA.x} {nB.xyz, uvA.y} {nC.xyz, uvB.x} {tA.xyz, uvB.y} {tB.xyz, uvC.x} {tC.xyz, uvC.y} {mat,-,-,-}
 struct TriShade {
-    uint32_t va, vb, vc, mat;
+    float q[6][4];
+    uint32_t mat, pad[3];
 };
 
-struct DevMaterial { // 64 B
+// A texture as a material sees it, 16 B so it rides inside the material record (no second,
+// dependent descriptor fetch).  kind RGK_TEXREF_NONE = EmptyTexture (id -1: black, Empty()).
+// SOLID: a,b,c = colour (float bits).  IMAGE: a = width | height << 16, b = index of texel (0,0)
+// in the float4 texel pool.
+#define RGK_TEXREF_NONE 0xffffffffu
+struct TexRef {
+    uint32_t kind, a, b, c;
+};
+
+struct DevMaterial { // 96 B = 6 x 16 B
     uint32_t kind, flags;
+    float roughness, ior;
     float emission[3];
-    float roughness, ior, amount;
-    int32_t tex_diffuse, tex_color, tex_bump;
+    float amount;
     int32_t mix_m1, mix_m2;
-    int32_t pad[3];
-};
-
-struct DevTexture { // 32 B
-    uint32_t kind, width, height;
-    float color[3];
-    uint32_t offset; // float offset of texel (0,0) in the texel pool
-    uint32_t pad;
+    int32_t pad[2];
+    TexRef t_diffuse, t_color, t_bump;
 };
 
 struct DevPointLight {
@@ -118,15 +120,13 @@ struct DevScene {
     const QNode* nodes;
     const TriIsect* tris;
     const TriShade* tri_shade;
-    const VtxAttr* vtx;
     const DevMaterial* materials;
-    const DevTexture* textures;
-    const float* texels;
+    const float4* texels; // RGBA float, A unused: one 16-byte load per texel
     const DevPointLight* pointlights;
     const DevArealLight* areal;
     const DevArealTri* areal_tris;
-    const float* ltc_ggx;      // 4096 x {m0,m2,m4,m6,amp}
-    const float* ltc_beckmann;
+    const float4* ltc_ggx;      // 4096 x {m0,m2,m4,m6}{amp,0,0,0}
+    const float4* ltc_beckmann;
     const DevHaltonDim* hdims;
     const uint16_t* hperm;
     uint32_t n_pointlights, n_areal;
@@ -137,7 +137,5 @@ struct DevScene {
     uint32_t sky_mode;
     float sky_color[3];
     float sky_intensity, sky_rotate;
-    int32_t sky_texture;
-    int32_t root_is_leaf; // scenes with a single leaf
-    int32_t root_leaf;
+    TexRef sky_tex;
 };

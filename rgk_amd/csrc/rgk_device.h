@@ -186,16 +186,16 @@ __device__ __forceinline__ bool decide_and_rescale(float& sample, float probabil
 
 // ------------------------------------------------------------------ textures (a14)
 __device__ __forceinline__ float glm_repeat(float x) { return x - floorf(x); }
-__device__ __forceinline__ f3 texel_at(const DevScene& sc, const DevTexture& t, int idx) {
-    const float* p = sc.texels + t.offset + 3 * (size_t)idx;
-    return mk3(p[0], p[1], p[2]);
+__device__ __forceinline__ f3 texel_at(const DevScene& sc, uint32_t first, int idx) {
+    const float4 t = sc.texels[first + (uint32_t)idx];
+    return mk3(t.x, t.y, t.z);
 }
-// ReadableTexture::GetPixelInterpolated, reference src/texture.cpp:35-77; id<0 = EmptyTexture
-__device__ inline f3 tex_get(const DevScene& sc, int id, float2 uv) {
-    if (id < 0) return mk3(0.f, 0.f, 0.f);
-    const DevTexture t = sc.textures[id];
-    if (t.kind == 0) return mk3(t.color[0], t.color[1], t.color[2]);
-    int xsize = (int)t.width, ysize = (int)t.height;
+// ReadableTexture::GetPixelInterpolated, reference src/texture.cpp:35-77 (FileTexture) and
+// src/texture.hpp:64-80 (Solid / Empty)
+__device__ inline f3 tex_get(const DevScene& sc, const TexRef t, float2 uv) {
+    if (t.kind == RGK_TEXREF_NONE) return mk3(0.f, 0.f, 0.f);
+    if (t.kind == RGK_TEX_SOLID) return mk3(__uint_as_float(t.a), __uint_as_float(t.b), __uint_as_float(t.c));
+    const int xsize = (int)(t.a & 0xffffu), ysize = (int)(t.a >> 16);
     float x = glm_repeat(uv.x) * xsize - 0.5f;
     float y = glm_repeat(uv.y) * ysize - 0.5f;
     float ix0f = truncf(x), iy0f = truncf(y);
@@ -205,8 +205,8 @@ __device__ inline f3 tex_get(const DevScene& sc, int id, float2 uv) {
     int iy1 = (iy0 != ysize - 1) ? iy0 + 1 : iy0;
     if (ix0 == -1) ix0 = 0;
     if (iy0 == -1) iy0 = 0;
-    f3 c00 = texel_at(sc, t, iy0 * xsize + ix0), c01 = texel_at(sc, t, iy0 * xsize + ix1);
-    f3 c10 = texel_at(sc, t, iy1 * xsize + ix0), c11 = texel_at(sc, t, iy1 * xsize + ix1);
+    f3 c00 = texel_at(sc, t.b, iy0 * xsize + ix0), c01 = texel_at(sc, t.b, iy0 * xsize + ix1);
+    f3 c10 = texel_at(sc, t.b, iy1 * xsize + ix0), c11 = texel_at(sc, t.b, iy1 * xsize + ix1);
     fy = 1.0f - fy;
     fx = 1.0f - fx;
     f3 c0s = fx * c00 + (1.0f - fx) * c01;
@@ -214,20 +214,19 @@ __device__ inline f3 tex_get(const DevScene& sc, int id, float2 uv) {
     return fy * c0s + (1.0f - fy) * c1s;
 }
 // GetSlopeRight / GetSlopeBottom, reference src/texture.cpp:79-102
-__device__ inline void tex_slopes(const DevScene& sc, int id, float2 uv, float& right, float& bottom) {
+__device__ inline void tex_slopes(const DevScene& sc, const TexRef t, float2 uv, float& right, float& bottom) {
     right = 0.f; bottom = 0.f;
-    const DevTexture t = sc.textures[id];
-    if (t.kind == 0) return;
-    int xsize = (int)t.width, ysize = (int)t.height;
+    if (t.kind != RGK_TEX_RGB32F) return;
+    const int xsize = (int)(t.a & 0xffffu), ysize = (int)(t.a >> 16);
     int x = (int)(glm_repeat(uv.x) * xsize - 0.5f);
     int y = (int)(glm_repeat(uv.y) * ysize - 0.5f);
     int x2 = (x != xsize - 1) ? x + 1 : x;
     int y2 = (y != ysize - 1) ? y + 1 : y;
     if (x == -1) x = 0;
     if (y == -1) y = 0;
-    f3 here = texel_at(sc, t, y * xsize + x);
-    f3 tr = texel_at(sc, t, y * xsize + x2);
-    f3 tb = texel_at(sc, t, y2 * xsize + x);
+    f3 here = texel_at(sc, t.b, y * xsize + x);
+    f3 tr = texel_at(sc, t.b, y * xsize + x2);
+    f3 tb = texel_at(sc, t.b, y2 * xsize + x);
     float a = (here.x + here.y + here.z) / 3;
     right = a - (tr.x + tr.y + tr.z) / 3;
     bottom = a - (tb.x + tb.y + tb.z) / 3;
@@ -239,8 +238,8 @@ __device__ inline void tex_slopes(const DevScene& sc, int id, float2 uv, float& 
 struct LtcM {
     float m0, m2, m4, m6, m8, amp;
 };
-// LTC::get_bilinear, reference src/LTC/ltc.cpp:20-57
-__device__ inline LtcM ltc_bilinear(const float* tab, float theta, float alpha) {
+// LTC::get_bilinear, reference src/LTC/ltc.cpp:20-57.  Table entry = {m0,m2,m4,m6}{amp,-,-,-}.
+__device__ inline LtcM ltc_bilinear(const float4* tab, float theta, float alpha) {
     float t = fmaxf(0.0f, fminf(1.0f, theta / (0.5f * 3.14159f)));
     float a = fmaxf(0.0f, fminf(1.0f, sqrtf(alpha)));
     if (t >= 1.0f) t = 0.999f;
@@ -248,14 +247,15 @@ __device__ inline LtcM ltc_bilinear(const float* tab, float theta, float alpha) 
     const int s = 63;
     int t1 = (int)floorf(t * s), t2 = t1 + 1;
     int a1 = (int)floorf(a * s), a2 = a1 + 1;
-    const float* e11 = tab + 5 * (a1 + t1 * 64);
-    const float* e12 = tab + 5 * (a2 + t1 * 64);
-    const float* e21 = tab + 5 * (a1 + t2 * 64);
-    const float* e22 = tab + 5 * (a2 + t2 * 64);
+    const float4 m11 = tab[2 * (a1 + t1 * 64)], m12 = tab[2 * (a2 + t1 * 64)], m21 = tab[2 * (a1 + t2 * 64)], m22 = tab[2 * (a2 + t2 * 64)];
+    const float p11 = tab[2 * (a1 + t1 * 64) + 1].x, p12 = tab[2 * (a2 + t1 * 64) + 1].x, p21 = tab[2 * (a1 + t2 * 64) + 1].x,
+                p22 = tab[2 * (a2 + t2 * 64) + 1].x;
     float dt1 = t * s - t1, dt2 = t2 - t * s, da1 = a * s - a1, da2 = a2 - a * s;
-#define RGK_BIL(k) (e11[k] * dt2 * da2 + e12[k] * dt2 * da1 + e21[k] * dt1 * da2 + e22[k] * dt1 * da1)
+#define RGK_BIL(e11, e12, e21, e22) ((e11) * dt2 * da2 + (e12) * dt2 * da1 + (e21) * dt1 * da2 + (e22) * dt1 * da1)
     LtcM r;
-    r.m0 = RGK_BIL(0); r.m2 = RGK_BIL(1); r.m4 = RGK_BIL(2); r.m6 = RGK_BIL(3); r.amp = RGK_BIL(4);
+    r.m0 = RGK_BIL(m11.x, m12.x, m21.x, m22.x); r.m2 = RGK_BIL(m11.y, m12.y, m21.y, m22.y);
+    r.m4 = RGK_BIL(m11.z, m12.z, m21.z, m22.z); r.m6 = RGK_BIL(m11.w, m12.w, m21.w, m22.w);
+    r.amp = RGK_BIL(p11, p12, p21, p22);
 #undef RGK_BIL
     r.m8 = dt2 * da2 + dt2 * da1 + dt1 * da2 + dt1 * da1; // the constant-1 entry, interpolated like the rest
     return r;
@@ -296,10 +296,10 @@ __device__ inline f3 ltc_random_M(const LtcM& M, f3 Vi, f3 rnd) {
     f3 r = mk3(Vi.x * s.x + (-Vi.y) * s.y, Vi.y * s.x + Vi.x * s.y, s.z);
     return norm3(r);
 }
-__device__ inline float ltc_pdf(const float* tab, f3 A, f3 B, float alpha) {
+__device__ inline float ltc_pdf(const float4* tab, f3 A, f3 B, float alpha) {
     return ltc_pdf_M(ltc_bilinear(tab, ltc_theta(B), alpha), A, B);
 }
-__device__ inline f3 ltc_random(const float* tab, f3 Vi, float roughness, f3 rnd) {
+__device__ inline f3 ltc_random(const float4* tab, f3 Vi, float roughness, f3 rnd) {
     return ltc_random_M(ltc_bilinear(tab, fmaxf(ltc_theta(Vi), RGK_PI_F / 4.0f), roughness), Vi, rnd);
 }
 
@@ -322,16 +322,16 @@ __device__ inline f3 bxdf_value_leaf(const DevScene& sc, const DevMaterial& m, f
     switch (m.kind) {
     case RGK_BXDF_DIFFUSE:
         if (Vi.z <= 0 || Vr.z <= 0) return zero;
-        return tex_get(sc, m.tex_diffuse, uv) / RGK_PI_F;
+        return tex_get(sc, m.t_diffuse, uv) / RGK_PI_F;
     case RGK_BXDF_MIRROR: {
         f3 refl = mk3(-Vi.x, -Vi.y, Vi.z);
-        return (fabsf(dot3(refl, Vr) - 1) < 0.0001f) ? tex_get(sc, m.tex_color, uv) : zero;
+        return (fabsf(dot3(refl, Vr) - 1) < 0.0001f) ? tex_get(sc, m.t_color, uv) : zero;
     }
     case RGK_BXDF_DIELECTRIC: {
         float eta = (Vi.z < 0) ? m.ior : (float)(1.0 / (double)m.ior);
         float R, cosT;
         fresnel_dielectric(eta, Vi.z, R, cosT);
-        f3 c = tex_get(sc, m.tex_color, uv);
+        f3 c = tex_get(sc, m.t_color, uv);
         if (Vi.z * Vr.z > 0) {
             f3 refl = mk3(-Vi.x, -Vi.y, Vi.z);
             return (fabsf(dot3(Vr, refl) - 1) < 0.001f) ? mk3(R, R, R) * c : zero;
@@ -347,15 +347,15 @@ __device__ inline f3 bxdf_value_leaf(const DevScene& sc, const DevMaterial& m, f
     case RGK_BXDF_LTC_BECKMANN:
     case RGK_BXDF_LTC_GGX: {
         if (Vi.z <= 0 || Vr.z <= 0) return zero;
-        const float* tab = (m.kind == RGK_BXDF_LTC_GGX) ? sc.ltc_ggx : sc.ltc_beckmann;
-        return tex_get(sc, m.tex_color, uv) * ltc_pdf(tab, Vi, Vr, m.roughness);
+        const float4* tab = (m.kind == RGK_BXDF_LTC_GGX) ? sc.ltc_ggx : sc.ltc_beckmann;
+        return tex_get(sc, m.t_color, uv) * ltc_pdf(tab, Vi, Vr, m.roughness);
     }
     case RGK_BXDF_LTC_BECKMANN_DIFFUSE:
     case RGK_BXDF_LTC_GGX_DIFFUSE: {
         if (Vi.z <= 0 || Vr.z <= 0) return zero;
-        const float* tab = (m.kind == RGK_BXDF_LTC_GGX_DIFFUSE) ? sc.ltc_ggx : sc.ltc_beckmann;
-        f3 diff = tex_get(sc, m.tex_diffuse, uv);
-        f3 spec = tex_get(sc, m.tex_color, uv);
+        const float4* tab = (m.kind == RGK_BXDF_LTC_GGX_DIFFUSE) ? sc.ltc_ggx : sc.ltc_beckmann;
+        f3 diff = tex_get(sc, m.t_diffuse, uv);
+        f3 spec = tex_get(sc, m.t_color, uv);
         return spec * ltc_pdf(tab, Vi, Vr, m.roughness) + diff / RGK_PI_F;
     }
     default: return zero;
@@ -394,17 +394,17 @@ __device__ inline void bxdf_sample(const DevScene& sc, int mat, f3 Vi, float2 uv
     case RGK_BXDF_DIFFUSE:
         if (Vi.z <= 0) { dir = mk3(0.f, 1.f, 0.f); weight = zero; return; }
         dir = hemisphere_cosine_z(u);
-        weight = tex_get(sc, m.tex_diffuse, uv);
+        weight = tex_get(sc, m.t_diffuse, uv);
         return;
     case RGK_BXDF_MIRROR:
         dir = mk3(-Vi.x, -Vi.y, Vi.z);
-        weight = tex_get(sc, m.tex_color, uv);
+        weight = tex_get(sc, m.t_color, uv);
         return;
     case RGK_BXDF_DIELECTRIC: {
         float eta = (Vi.z < 0) ? m.ior : (float)(1.0 / (double)m.ior);
         float R, cosT;
         fresnel_dielectric(eta, fabsf(Vi.z), R, cosT);
-        weight = tex_get(sc, m.tex_color, uv);
+        weight = tex_get(sc, m.t_color, uv);
         if (decide_and_rescale(u.x, R)) { dir = mk3(-Vi.x, -Vi.y, Vi.z); return; }
         cosT = fabsf(cosT);
         dir = mk3(-Vi.x * eta, -Vi.y * eta, (Vi.z > 0) ? -cosT : cosT);
@@ -418,17 +418,17 @@ __device__ inline void bxdf_sample(const DevScene& sc, int mat, f3 Vi, float2 uv
         return;
     case RGK_BXDF_LTC_BECKMANN:
     case RGK_BXDF_LTC_GGX: {
-        const float* tab = (m.kind == RGK_BXDF_LTC_GGX) ? sc.ltc_ggx : sc.ltc_beckmann;
+        const float4* tab = (m.kind == RGK_BXDF_LTC_GGX) ? sc.ltc_ggx : sc.ltc_beckmann;
         f3 v = ltc_random(tab, Vi, m.roughness, hemisphere_cosine_z(u));
         dir = v;
-        weight = (v.z <= 0) ? zero : tex_get(sc, m.tex_color, uv);
+        weight = (v.z <= 0) ? zero : tex_get(sc, m.t_color, uv);
         return;
     }
     case RGK_BXDF_LTC_BECKMANN_DIFFUSE:
     case RGK_BXDF_LTC_GGX_DIFFUSE: {
-        const float* tab = (m.kind == RGK_BXDF_LTC_GGX_DIFFUSE) ? sc.ltc_ggx : sc.ltc_beckmann;
-        f3 diff = tex_get(sc, m.tex_diffuse, uv);
-        f3 spec = tex_get(sc, m.tex_color, uv);
+        const float4* tab = (m.kind == RGK_BXDF_LTC_GGX_DIFFUSE) ? sc.ltc_ggx : sc.ltc_beckmann;
+        f3 diff = tex_get(sc, m.t_diffuse, uv);
+        f3 spec = tex_get(sc, m.t_color, uv);
         float dp = diff.x + diff.y + diff.z, sp = spec.x + spec.y + spec.z;
         float prob = dp / (dp + sp + 0.0001f);
         if (decide_and_rescale(u.x, prob)) {
@@ -457,21 +457,21 @@ struct MatPrep {
     f3 diffc, colorc;
     LtcM Mv, Ms;
 };
-__device__ inline void mat_prepare(const DevScene& sc, const DevMaterial& m, float2 uv, f3 VrL, MatPrep& e) {
+__device__ inline void mat_prepare(const DevScene& sc, const DevMaterial& m, float2 uv, f3 VrL, bool need_sample, MatPrep& e) {
     e.fast = false;
     e.diffc = e.colorc = mk3(0.f, 0.f, 0.f);
     const uint32_t k = m.kind;
     if (k == RGK_BXDF_DIFFUSE) {
         e.fast = true;
-        e.diffc = tex_get(sc, m.tex_diffuse, uv);
+        e.diffc = tex_get(sc, m.t_diffuse, uv);
     } else if (k >= RGK_BXDF_LTC_BECKMANN) {
         e.fast = true;
-        e.colorc = tex_get(sc, m.tex_color, uv);
-        if (k >= RGK_BXDF_LTC_BECKMANN_DIFFUSE) e.diffc = tex_get(sc, m.tex_diffuse, uv);
-        const float* tab = (k == RGK_BXDF_LTC_GGX || k == RGK_BXDF_LTC_GGX_DIFFUSE) ? sc.ltc_ggx : sc.ltc_beckmann;
+        e.colorc = tex_get(sc, m.t_color, uv);
+        if (k >= RGK_BXDF_LTC_BECKMANN_DIFFUSE) e.diffc = tex_get(sc, m.t_diffuse, uv);
+        const float4* tab = (k == RGK_BXDF_LTC_GGX || k == RGK_BXDF_LTC_GGX_DIFFUSE) ? sc.ltc_ggx : sc.ltc_beckmann;
         const float theta = ltc_theta(VrL);
         e.Mv = ltc_bilinear(tab, theta, m.roughness);
-        e.Ms = (theta >= RGK_PI_F / 4.0f) ? e.Mv : ltc_bilinear(tab, RGK_PI_F / 4.0f, m.roughness);
+        e.Ms = (theta >= RGK_PI_F / 4.0f || !need_sample) ? e.Mv : ltc_bilinear(tab, RGK_PI_F / 4.0f, m.roughness);
     }
 }
 __device__ inline void mat_sample(const DevScene& sc, int mat, const DevMaterial& m, const MatPrep& e, f3 VrL, float2 uv, float2 u,
@@ -612,6 +612,6 @@ __device__ inline f3 skybox(const DevScene& sc, f3 direction) {
     beta += sc.sky_rotate * 0.0174533f;
     float x = beta / (2.0f * RGK_PI_F) + 0.5f;
     float y = alpha / RGK_PI_F + 0.5f;
-    f3 c = tex_get(sc, sc.sky_texture, make_float2(x, y));
+    f3 c = tex_get(sc, sc.sky_tex, make_float2(x, y));
     return c * mk3(sc.sky_intensity, sc.sky_intensity, sc.sky_intensity);
 }

@@ -81,9 +81,12 @@ struct BvhBuilder {
     uint32_t max_depth = 0;
     float pad;
     static constexpr int NBINS = 16;
-    static constexpr int MAX_LEAF = 4;
-    static constexpr float C_TRAV = 1.0f, C_ISECT = 2.0f;
-    BvhBuilder(std::vector<Prim>& p, float pad_) : prims(p), pad(pad_) {}
+    int MAX_LEAF = 4;                      // leaf encoding allows up to 16
+    float C_TRAV = 1.0f, C_ISECT = 1.0f;   // SAH: one node step vs one triangle test (swept on MI355X: 1.0 best)
+    BvhBuilder(std::vector<Prim>& p, float pad_) : prims(p), pad(pad_) {
+        if (const char* e = getenv("RGK_BVH_MAXLEAF")) MAX_LEAF = std::min(16, std::max(1, atoi(e)));
+        if (const char* e = getenv("RGK_BVH_CISECT")) C_ISECT = (float)atof(e);
+    }
 
     int make_leaf(size_t b, size_t e) {
         uint32_t first = order.size();
@@ -235,7 +238,7 @@ struct QbvhBuilder {
                     lo[i] = (uint8_t)fl; hi[i] = (uint8_t)fh;
                 }
                 if (!ok) continue;
-                q.e[a] = (uint8_t)(e + 127);
+                (a == 0 ? q.sx : (a == 1 ? q.sy : q.sz)) = scale;
                 for (size_t i = 0; i < 4; i++) { q.qlo[a][i] = i < ch.size() ? lo[i] : 255; q.qhi[a][i] = i < ch.size() ? hi[i] : 0; }
                 break;
             }
@@ -290,14 +293,12 @@ struct rgk_scene {
     DevBuf<QNode> nodes;
     DevBuf<TriIsect> tris;
     DevBuf<TriShade> tri_shade;
-    DevBuf<VtxAttr> vtx;
     DevBuf<DevMaterial> materials;
-    DevBuf<DevTexture> textures;
-    DevBuf<float> texels;
+    DevBuf<float4> texels;
     DevBuf<DevPointLight> pointlights;
     DevBuf<DevArealLight> areal;
     DevBuf<DevArealTri> areal_tris;
-    DevBuf<float> ltc_ggx, ltc_beckmann;
+    DevBuf<float4> ltc_ggx, ltc_beckmann;
     DevBuf<DevHaltonDim> hdims;
     DevBuf<uint16_t> hperm;
     // workspace
@@ -315,7 +316,7 @@ struct rgk_scene {
         (void)hipSetDevice(device);
         for (auto e : events) (void)hipEventDestroy(e);
         if (h_counters) (void)hipHostFree(h_counters);
-        nodes.release(); tris.release(); tri_shade.release(); vtx.release(); materials.release(); textures.release();
+        nodes.release(); tris.release(); tri_shade.release(); materials.release();
         texels.release(); pointlights.release(); areal.release(); areal_tris.release(); ltc_ggx.release();
         ltc_beckmann.release(); hdims.release(); hperm.release();
         for (int i = 0; i < 2; i++) { rayA[i].release(); rayB[i].release(); }
@@ -517,7 +518,7 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
         bb.nodes.reserve(prims.size());
         bb.nodes.emplace_back(); // node 0 = root, filled below if the whole scene is one leaf
         int code;
-        if (prims.size() <= (size_t)BvhBuilder::MAX_LEAF) {
+        if (prims.size() <= (size_t)bb.MAX_LEAF) {
             code = bb.build(0, prims.size(), 1, rootbox);
             BvhNode& r = bb.nodes[0];
             for (int a = 0; a < 3; a++) {
@@ -545,15 +546,39 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
 
     // ---- shading arrays
     std::vector<TriShade> tsh(nt);
-    for (uint32_t i = 0; i < nt; i++) tsh[i] = TriShade{d->tri_indices[3 * i], d->tri_indices[3 * i + 1], d->tri_indices[3 * i + 2], d->tri_material[i]};
-    std::vector<VtxAttr> vtx(nv);
-    for (uint32_t i = 0; i < nv; i++) {
-        VtxAttr& v = vtx[i];
-        v.nx = d->normals[3 * i]; v.ny = d->normals[3 * i + 1]; v.nz = d->normals[3 * i + 2];
-        v.tx = d->tangents[3 * i]; v.ty = d->tangents[3 * i + 1]; v.tz = d->tangents[3 * i + 2];
-        v.u = d->texcoords ? d->texcoords[2 * i] : 0.f;
-        v.v = d->texcoords ? d->texcoords[2 * i + 1] : 0.f;
+    for (uint32_t i = 0; i < nt; i++) {
+        TriShade& t = tsh[i];
+        std::memset(&t, 0, sizeof(t));
+        const uint32_t v[3] = {d->tri_indices[3 * i], d->tri_indices[3 * i + 1], d->tri_indices[3 * i + 2]};
+        float uvs[6];
+        for (int k = 0; k < 3; k++) {
+            for (int a = 0; a < 3; a++) { t.q[k][a] = d->normals[3 * v[k] + a]; t.q[3 + k][a] = d->tangents[3 * v[k] + a]; }
+            uvs[2 * k] = d->texcoords ? d->texcoords[2 * v[k]] : 0.f;
+            uvs[2 * k + 1] = d->texcoords ? d->texcoords[2 * v[k] + 1] : 0.f;
+        }
+        for (int k = 0; k < 6; k++) t.q[k][3] = uvs[k]; // uvA.x uvA.y uvB.x uvB.y uvC.x uvC.y
+        t.mat = d->tri_material[i];
     }
+    // textures: image texels into one float4 pool; a TexRef per (material, slot)
+    std::vector<float4> pool;
+    std::vector<TexRef> trefs(d->n_textures);
+    for (uint32_t i = 0; i < d->n_textures; i++) {
+        const rgk_texture& t = d->textures[i];
+        TexRef& o = trefs[i];
+        o.kind = t.kind; o.a = o.b = o.c = 0;
+        if (t.kind == RGK_TEX_SOLID) {
+            std::memcpy(&o.a, &t.color[0], 4); std::memcpy(&o.b, &t.color[1], 4); std::memcpy(&o.c, &t.color[2], 4);
+        } else {
+            if (t.width > 65535 || t.height > 65535) return fail(RGK_ERR_UNSUPPORTED, "texture %u larger than 65535 texels on a side", i);
+            const size_t n = (size_t)t.width * t.height;
+            if (pool.size() + n >= (1ull << 32)) return fail(RGK_ERR_UNSUPPORTED, "texel pool exceeds 2^32 texels");
+            o.a = t.width | (t.height << 16);
+            o.b = (uint32_t)pool.size();
+            pool.reserve(pool.size() + n);
+            for (size_t k = 0; k < n; k++) pool.push_back(make_float4(t.texels[3 * k], t.texels[3 * k + 1], t.texels[3 * k + 2], 0.f));
+        }
+    }
+    auto tref = [&](int32_t id) { TexRef r; r.kind = RGK_TEXREF_NONE; r.a = r.b = r.c = 0; return id < 0 ? r : trefs[id]; };
     std::vector<DevMaterial> mats(d->n_materials);
     for (uint32_t i = 0; i < d->n_materials; i++) {
         const rgk_material& m = d->materials[i];
@@ -562,22 +587,8 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
         o.kind = m.kind; o.flags = m.flags;
         for (int k = 0; k < 3; k++) o.emission[k] = m.emission[k];
         o.roughness = m.roughness; o.ior = m.ior; o.amount = m.amount;
-        o.tex_diffuse = m.tex_diffuse; o.tex_color = m.tex_color; o.tex_bump = m.tex_bump;
+        o.t_diffuse = tref(m.tex_diffuse); o.t_color = tref(m.tex_color); o.t_bump = tref(m.tex_bump);
         o.mix_m1 = m.mix_m1; o.mix_m2 = m.mix_m2;
-    }
-    std::vector<DevTexture> texs(d->n_textures);
-    std::vector<float> pool;
-    for (uint32_t i = 0; i < d->n_textures; i++) {
-        const rgk_texture& t = d->textures[i];
-        DevTexture& o = texs[i];
-        std::memset(&o, 0, sizeof(o));
-        o.kind = t.kind; o.width = t.width; o.height = t.height;
-        for (int k = 0; k < 3; k++) o.color[k] = t.color[k];
-        if (t.kind == RGK_TEX_RGB32F) {
-            if (pool.size() + (size_t)3 * t.width * t.height >= (1ull << 32)) return fail(RGK_ERR_UNSUPPORTED, "texel pool exceeds 2^32 floats");
-            o.offset = (uint32_t)pool.size();
-            pool.insert(pool.end(), t.texels, t.texels + (size_t)3 * t.width * t.height);
-        }
     }
     // ---- lights (scene.cpp:323-344)
     std::vector<DevPointLight> pls(d->n_pointlights);
@@ -633,14 +644,21 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
 
     // ---- upload
     if ((rc = s->nodes.upload(qb.out)) || (rc = s->tris.upload(leaf_recs)) || (rc = s->tri_shade.upload(tsh)) ||
-        (rc = s->vtx.upload(vtx)) || (rc = s->materials.upload(mats)) || (rc = s->textures.upload(texs)) ||
-        (rc = s->texels.upload(pool)) || (rc = s->pointlights.upload(pls)) || (rc = s->areal.upload(als)) ||
+        (rc = s->materials.upload(mats)) || (rc = s->texels.upload(pool)) || (rc = s->pointlights.upload(pls)) || (rc = s->areal.upload(als)) ||
         (rc = s->areal_tris.upload(ats)) || (rc = s->hdims.upload(hd)) || (rc = s->hperm.upload(hp)))
         return rc;
-    if (d->ltc_ggx) { std::vector<float> t(d->ltc_ggx, d->ltc_ggx + 5 * 4096); if ((rc = s->ltc_ggx.upload(t))) return rc; }
-    if (d->ltc_beckmann) { std::vector<float> t(d->ltc_beckmann, d->ltc_beckmann + 5 * 4096); if ((rc = s->ltc_beckmann.upload(t))) return rc; }
-    ds.nodes = s->nodes.p; ds.tris = s->tris.p; ds.tri_shade = s->tri_shade.p; ds.vtx = s->vtx.p;
-    ds.materials = s->materials.p; ds.textures = s->textures.p; ds.texels = s->texels.p;
+    auto ltc_pack = [](const float* src) { // {m0,m2,m4,m6}{amp,0,0,0} per entry: two 16-byte loads
+        std::vector<float4> t(2 * 4096);
+        for (int k = 0; k < 4096; k++) {
+            t[2 * k] = make_float4(src[5 * k], src[5 * k + 1], src[5 * k + 2], src[5 * k + 3]);
+            t[2 * k + 1] = make_float4(src[5 * k + 4], 0.f, 0.f, 0.f);
+        }
+        return t;
+    };
+    if (d->ltc_ggx && (rc = s->ltc_ggx.upload(ltc_pack(d->ltc_ggx)))) return rc;
+    if (d->ltc_beckmann && (rc = s->ltc_beckmann.upload(ltc_pack(d->ltc_beckmann)))) return rc;
+    ds.nodes = s->nodes.p; ds.tris = s->tris.p; ds.tri_shade = s->tri_shade.p;
+    ds.materials = s->materials.p; ds.texels = s->texels.p;
     ds.pointlights = s->pointlights.p; ds.areal = s->areal.p; ds.areal_tris = s->areal_tris.p;
     ds.ltc_ggx = s->ltc_ggx.p; ds.ltc_beckmann = s->ltc_beckmann.p; ds.hdims = s->hdims.p; ds.hperm = s->hperm.p;
     ds.n_pointlights = (uint32_t)pls.size(); ds.n_areal = (uint32_t)als.size();
@@ -648,7 +666,7 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
     ds.has_texcoords = d->texcoords ? 1u : 0u;
     ds.sky_mode = d->sky_mode;
     for (int k = 0; k < 3; k++) ds.sky_color[k] = d->sky_color[k];
-    ds.sky_intensity = d->sky_intensity; ds.sky_rotate = d->sky_rotate; ds.sky_texture = d->sky_texture;
+    ds.sky_intensity = d->sky_intensity; ds.sky_rotate = d->sky_rotate; ds.sky_tex = tref(d->sky_mode == RGK_SKY_ENVMAP ? d->sky_texture : -1);
 
     rgk_scene_info& inf = s->info;
     inf.epsilon = eps;

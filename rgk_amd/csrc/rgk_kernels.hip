@@ -104,15 +104,15 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade(const DevScene sc,
                 t.x = t.x + add.x; t.y = t.y + add.y; t.z = t.z + add.z;
                 tot[slot] = t;
             } else {
-                const TriShade ts = sc.tri_shade[tri];
+                // one contiguous 112-byte record per triangle: {nA,uvA.x}{nB,uvA.y}{nC,uvB.x}{tA,uvB.y}{tB,uvC.x}{tC,uvC.y}{mat}
+                const float4* tsr = reinterpret_cast<const float4*>(sc.tri_shade) + 7 * (size_t)tri;
+                const float4 g0 = tsr[0], g1 = tsr[1], g2 = tsr[2];
+                const uint32_t mat_id = __float_as_uint(tsr[6].x);
+                const DevMaterial mat = sc.materials[mat_id];
                 const float al = h.y, be = h.z;
                 const float ia = 1.0f - al - be, ib = al, ic = be; // Intersection::a,b,c scene_intersect.cpp:280-283
-                const float4* vtx = reinterpret_cast<const float4*>(sc.vtx);
-                const float4 va0 = vtx[2 * ts.va], va1 = vtx[2 * ts.va + 1];
-                const float4 vb0 = vtx[2 * ts.vb], vb1 = vtx[2 * ts.vb + 1];
-                const float4 vc0 = vtx[2 * ts.vc], vc1 = vtx[2 * ts.vc + 1];
                 f3 pos = o + h.x * d;
-                f3 nA_ = mk3(va0.x, va0.y, va0.z), nB_ = mk3(vb0.x, vb0.y, vb0.z), nC_ = mk3(vc0.x, vc0.y, vc0.z);
+                f3 nA_ = mk3(g0.x, g0.y, g0.z), nB_ = mk3(g1.x, g1.y, g1.z), nC_ = mk3(g2.x, g2.y, g2.z);
                 f3 faceN = ia * nA_ + ib * nB_ + ic * nC_;
                 bool ok = true;
                 if (faceN.x != faceN.x) { // NaN fallbacks, path_tracer.cpp:157-171
@@ -122,17 +122,17 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade(const DevScene sc,
                 if (ok && len3(faceN) <= 0.0f) ok = false; // path_tracer.cpp:175
                 if (ok) {
                     faceN = norm3(faceN);
-                    const DevMaterial mat = sc.materials[ts.mat];
+                    const float4 g3 = tsr[3], g4 = tsr[4], g5 = tsr[5];
                     float2 uv = make_float2(0.f, 0.f);
                     if (sc.has_texcoords) {
-                        uv.x = ia * va0.w + ib * vb0.w + ic * vc0.w;
-                        uv.y = ia * va1.w + ib * vb1.w + ic * vc1.w;
+                        uv.x = ia * g0.w + ib * g2.w + ic * g4.w;
+                        uv.y = ia * g1.w + ib * g3.w + ic * g5.w;
                     }
                     f3 lightN = faceN;
-                    if (mat.tex_bump >= 0) { // bump, path_tracer.cpp:204-231
+                    if (mat.t_bump.kind != RGK_TEXREF_NONE) { // bump, path_tracer.cpp:204-231
                         float right, bottom;
-                        tex_slopes(sc, mat.tex_bump, uv, right, bottom);
-                        f3 tangent = ia * mk3(va1.x, va1.y, va1.z) + ib * mk3(vb1.x, vb1.y, vb1.z) + ic * mk3(vc1.x, vc1.y, vc1.z);
+                        tex_slopes(sc, mat.t_bump, uv, right, bottom);
+                        f3 tangent = ia * mk3(g3.x, g3.y, g3.z) + ib * mk3(g4.x, g4.y, g4.z) + ic * mk3(g5.x, g5.y, g5.z);
                         if (!(tangent.x * tangent.x + tangent.y * tangent.y + tangent.z * tangent.z < 0.001f)) {
                             tangent = norm3(tangent);
                             f3 bitangent = norm3(cross3(faceN, tangent));
@@ -143,23 +143,30 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade(const DevScene sc,
                     }
                     // SystemTransform(lightN, +Z), reference src/glm.hpp:21-24
                     const quatf g2l = rotation_between(lightN, mk3(0.f, 0.f, 1.f));
-                    const quatf l2g = qinverse(g2l);
                     const f3 VrL = qrot(g2l, Vr);
-                    // BxDF sample, path_tracer.cpp:243-250
-                    float2 u = sample2d_t(tb, seed, s, base2d + 3u + (n - 1u));
-                    f3 dirL, weight; bool may_leak;
+                    // The vertex at n == depth is the path's last (while(n < depth__), :122): its sampled direction,
+                    // transfer coefficient and roulette draw can never be observed, so they are not computed.
+                    const bool last = !(n < pp.depth);
                     MatPrep mp;
-                    mat_prepare(sc, mat, uv, VrL, mp);
-                    mat_sample(sc, (int)ts.mat, mat, mp, VrL, uv, u, dirL, weight, may_leak);
-                    const bool inside = dirL.z < 0;
-                    f3 dir = qrot(l2g, dirL);
-                    uint32_t n_eff = n;
-                    if (!(dot3(dir, faceN) * dot3(Vr, faceN) > 0) && !may_leak) n_eff += 10000u; // leak, :252-260
+                    mat_prepare(sc, mat, uv, VrL, !last, mp);
                     const bool no_russian = (mat.flags & RGK_MAT_NO_RUSSIAN) != 0;
-                    const float rc = (!no_russian && pp.russian > 0.0f && n_eff > 1u) ? 1.0f / pp.russian : 1.0f;
                     const f3 contribution = cum; // excludes this vertex's own coefficients, :135
-                    cum = cum * rc;
-                    cum = cum * weight;
+                    bool inside = false;
+                    f3 dir = mk3(0.f, 0.f, 0.f);
+                    uint32_t n_eff = n;
+                    if (!last) {
+                        // BxDF sample, path_tracer.cpp:243-250
+                        const quatf l2g = qinverse(g2l);
+                        float2 u = sample2d_t(tb, seed, s, base2d + 3u + (n - 1u));
+                        f3 dirL, weight; bool may_leak;
+                        mat_sample(sc, (int)mat_id, mat, mp, VrL, uv, u, dirL, weight, may_leak);
+                        inside = dirL.z < 0;
+                        dir = qrot(l2g, dirL);
+                        if (!(dot3(dir, faceN) * dot3(Vr, faceN) > 0) && !may_leak) n_eff += 10000u; // leak, :252-260
+                        const float rc = (!no_russian && pp.russian > 0.0f && n_eff > 1u) ? 1.0f / pp.russian : 1.0f;
+                        cum = cum * rc;
+                        cum = cum * weight;
+                    }
 
                     // ---- phase 3 for this vertex: NEE to the path's light, :427-460,485-496
                     {
@@ -180,7 +187,7 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade(const DevScene sc,
                             const f3 sd = norm3(diff);
                             const float slen = len3(diff);
                             const f3 Vi = norm3(L.pos - pos);
-                            const f3 f = mat_value(sc, (int)ts.mat, mat, mp, qrot(g2l, Vi), VrL, uv);
+                            const f3 f = mat_value(sc, (int)mat_id, mat, mp, qrot(g2l, Vi), VrL, uv);
                             const float G = fabsf(dot3(lightN, Vi)) / dot3(diff, diff);
                             const float k = L.intensity * light_dir_factor(L, -Vi);
                             const f3 inc = L.color * mk3(k, k, k);
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade(const DevScene sc,
                         }
                     }
                     // ---- continuation, path_tracer.cpp:275-300
-                    bool go = !(max3c(cum) < 0.001f);
+                    bool go = !last && !(max3c(cum) < 0.001f);
                     if (go && !no_russian && pp.russian >= 0.0f) {
                         float r = sample1d_t(tb, seed, s, c1);
                         c1++;

@@ -148,15 +148,15 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
             if (exhausted && w_next >= w_end) break;
             continue;
         }
-        // ------------------------------------------------ inner nodes: until this lane reaches a leaf or runs dry
+        // ------------------------------------------------ inner nodes: until this lane reaches a leaf or runs dry.
+        // (Postponing the first leaf and walking on -- "speculative traversal" -- was measured: 8 % more
+        // nodes, 30 % more triangle tests, 20 % slower.  Not kept.)
         while (active && cur >= 0 && cur != STACK_SENTINEL) {
-            // one 64-byte QNode: {p.xyz, exps} {child[4]} {qlo.x qlo.y qlo.z qhi.x} {qhi.y qhi.z - -}
+            // one 64-byte QNode: {p.xyz, sx} {child[4]} {qlo.x qlo.y qlo.z qhi.x} {qhi.y qhi.z sy sz}
             const float4 n0 = nodes[4 * cur + 0], n1 = nodes[4 * cur + 1], n2 = nodes[4 * cur + 2], n3 = nodes[4 * cur + 3];
             if (COUNT) n_nodes++;
             const float limit = ANY ? thi : fminf(thi, best_t);
-            const uint32_t ex = __float_as_uint(n0.w);
-            const float sx = __uint_as_float((ex & 0xffu) << 23), sy = __uint_as_float(((ex >> 8) & 0xffu) << 23),
-                        sz = __uint_as_float(((ex >> 16) & 0xffu) << 23);
+            const float sx = n0.w, sy = n3.z, sz = n3.w; // per-axis quantisation step (a power of two)
             // plane distance along the ray: t = (p + q*s - o) / d = q * (s/d) + (p - o)/d, one fma per plane.
             // The split loses a few ulps of |(p-o)/d| to cancellation; the child boxes carry an absolute
             // pad of eps = 1e-5 * scene diagonal, two orders above float resolution at scene scale, so the
@@ -193,10 +193,12 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
                           const int rr = sw ? ref[b] : ref[a], ru = sw ? ref[a] : ref[b]; te[a] = tt; te[b] = tu; ref[a] = rr; ref[b] = ru; }
                 RGK_CSWAP(0, 1) RGK_CSWAP(2, 3) RGK_CSWAP(0, 2) RGK_CSWAP(1, 3) RGK_CSWAP(1, 2)
 #undef RGK_CSWAP
-                // misses carry te = inf / ref = SENTINEL and sort to the back; push far -> near
-                if (ref[3] != STACK_SENTINEL && sp < STACK) { stack[sp * stride] = ref[3]; sp++; }
-                if (ref[2] != STACK_SENTINEL && sp < STACK) { stack[sp * stride] = ref[2]; sp++; }
-                if (ref[1] != STACK_SENTINEL && sp < STACK) { stack[sp * stride] = ref[1]; sp++; }
+                // misses carry te = inf / ref = SENTINEL and sort to the back; push far -> near.
+                // Branch-free: always write the next free entry, advance only for a real child (the host
+                // sized STACK above the deepest push sequence the tree can produce, rgk_host.cpp QbvhBuilder).
+                stack[sp * stride] = ref[3]; sp += (ref[3] != STACK_SENTINEL);
+                stack[sp * stride] = ref[2]; sp += (ref[2] != STACK_SENTINEL);
+                stack[sp * stride] = ref[1]; sp += (ref[1] != STACK_SENTINEL);
                 cur = ref[0];
             } else {
                 cur = STACK_SENTINEL; // any-hit: order is irrelevant; keep one hit child, push the rest
