@@ -1023,11 +1023,16 @@ struct Sampler {
     virtual void Advance() = 0;
     virtual float Get1D() = 0;
     virtual vec2 Get2D() = 0;
+    // position of the 2-D dimension counter (current_sample2D, src/sampler.hpp:62-66)
+    virtual unsigned Pos2D() const = 0;
+    virtual void Seek2D(unsigned k) = 0;
 };
 struct HaltonCPSampler : Sampler {
     uint32_t seed, set = (uint32_t)-1, c1 = 0, c2 = 0;
     HaltonCPSampler(uint32_t s) : seed(s) {}
     void Advance() override { c1 = 0; c2 = 0; set++; }
+    unsigned Pos2D() const override { return c2; }
+    void Seek2D(unsigned k) override { c2 = k; }
     // logical 2-D dimension k -> Halton dimensions (3k, 3k+1); logical 1-D dimension k -> 3k+2
     float Get1D() override { uint32_t k = c1++; return halton_cp(seed, set, k < 64 ? 3 * k + 2 : 192 + 3 * (k - 64) + 2); }
     vec2 Get2D() override {
@@ -1080,6 +1085,8 @@ struct StratifiedSampler : Sampler {
         if (current_set == (unsigned)-1) PrepareSamples();
         cur1 = 0; cur2 = 0; current_set++;
     }
+    unsigned Pos2D() const override { return cur2; }
+    void Seek2D(unsigned k) override { cur2 = k; }
     float Get1D() override {
         return (cur1 < dim_count) ? samples1D[cur1++][current_set] : std::uniform_real_distribution<float>(0.0f, 1.0f)(gen);
     }
@@ -1218,6 +1225,7 @@ struct PathTracer {
         vec2 choice = sampler.Get2D();
         float tri_pick = sampler.Get1D();
         Light main_light = scene.GetRandomLight(choice, tri_pick, areal_sample);
+        const unsigned bounce_dim0 = sampler.Pos2D();
 
         std::vector<PathPoint> path = GeneratePath(r, depth, russian, sampler);
 
@@ -1233,6 +1241,12 @@ struct PathTracer {
         std::vector<PathPoint> light_path;
         if (reverse > 0 && main_light.valid) {
             Ray light_ray(main_light.pos + scene.epsilon * main_light.normal * 100.0f, main_light_dir);
+            // Sampler contract: the light sub-path draws its BxDF samples from the 2-D
+            // dimensions after the `depth` reserved for the forward path, not from wherever the forward
+            // path happened to stop (reference: path_tracer.cpp:349 simply continues the counter).  Every
+            // table dimension is an independent sample set, so the estimator is unchanged; the fixed
+            // position lets the GPU generate the light sub-path before the forward path.
+            sampler.Seek2D(bounce_dim0 + depth);
             light_path = GeneratePath(light_ray, reverse, -1.0f, sampler);
         }
         Radiance light_at_path_start =

@@ -254,8 +254,8 @@ class Config:
         return p
 
     # ---- main.cpp:208-217 order: materials, scene, lights, sky, (thinglass), Commit
-    def build_scene(self, asset_dir=None, mesh_provider=None):
-        sb = SceneBuilder()
+    def build_scene(self, asset_dir=None, mesh_provider=None, builder=None):
+        sb = builder or SceneBuilder()
         self.install_materials(sb)
         self.install_scene(sb, asset_dir, mesh_provider)
         self.install_lights(sb)

@@ -615,3 +615,89 @@ __device__ inline f3 skybox(const DevScene& sc, f3 direction) {
     f3 c = tex_get(sc, sc.sky_tex, make_float2(x, y));
     return c * mk3(sc.sky_intensity, sc.sky_intensity, sc.sky_intensity);
 }
+
+// ------------------------------------------------------------------ path vertex (shared by the BDPT kernels)
+// The geometric half of one GeneratePath iteration, reference src/path_tracer.cpp:152-235: hit point,
+// interpolated + normalised face normal (with the NaN fallbacks), uv, bump-tilted shading normal and
+// the global->local frame.  `ok == false` is the reference's `return path` (vertex dropped, path ends).
+struct Vertex {
+    bool ok;
+    f3 pos, faceN, lightN, Vr, VrL;
+    float2 uv;
+    uint32_t mat_id;
+    DevMaterial mat;
+    quatf g2l;
+};
+__device__ __forceinline__ f3 clamp3(f3 v, float c) { return mk3(v.x > c ? c : v.x, v.y > c ? c : v.y, v.z > c ? c : v.z); }
+
+__device__ inline void surface_point(const DevScene& sc, float bumpmap_scale, f3 o, f3 d, float4 h, Vertex& v) {
+    const int tri = __float_as_int(h.w);
+    const float4* tsr = reinterpret_cast<const float4*>(sc.tri_shade) + 7 * (size_t)tri;
+    const float4 g0 = tsr[0], g1 = tsr[1], g2 = tsr[2];
+    v.mat_id = __float_as_uint(tsr[6].x);
+    v.mat = sc.materials[v.mat_id];
+    const float al = h.y, be = h.z;
+    const float ia = 1.0f - al - be, ib = al, ic = be; // Intersection::a,b,c scene_intersect.cpp:280-283
+    v.Vr = -d;
+    v.pos = o + h.x * d;
+    f3 nA_ = mk3(g0.x, g0.y, g0.z), nB_ = mk3(g1.x, g1.y, g1.z), nC_ = mk3(g2.x, g2.y, g2.z);
+    f3 faceN = ia * nA_ + ib * nB_ + ic * nC_;
+    v.ok = true;
+    if (faceN.x != faceN.x) { // NaN fallbacks, path_tracer.cpp:157-171
+        faceN = nA_;
+        if (faceN.x != faceN.x) { faceN = nB_; if (faceN.x != faceN.x) { faceN = nC_; if (faceN.x != faceN.x) v.ok = false; } }
+    }
+    if (v.ok && len3(faceN) <= 0.0f) v.ok = false; // path_tracer.cpp:175
+    v.uv = make_float2(0.f, 0.f);
+    v.faceN = v.lightN = faceN;
+    if (!v.ok) return;
+    faceN = norm3(faceN);
+    const float4 g3 = tsr[3], g4 = tsr[4], g5 = tsr[5];
+    if (sc.has_texcoords) {
+        v.uv.x = ia * g0.w + ib * g2.w + ic * g4.w;
+        v.uv.y = ia * g1.w + ib * g3.w + ic * g5.w;
+    }
+    f3 lightN = faceN;
+    if (v.mat.t_bump.kind != RGK_TEXREF_NONE) { // bump, path_tracer.cpp:204-231
+        float right, bottom;
+        tex_slopes(sc, v.mat.t_bump, v.uv, right, bottom);
+        f3 tangent = ia * mk3(g3.x, g3.y, g3.z) + ib * mk3(g4.x, g4.y, g4.z) + ic * mk3(g5.x, g5.y, g5.z);
+        if (!(tangent.x * tangent.x + tangent.y * tangent.y + tangent.z * tangent.z < 0.001f)) {
+            tangent = norm3(tangent);
+            f3 bitangent = norm3(cross3(faceN, tangent));
+            f3 tangent2 = cross3(bitangent, faceN);
+            lightN = norm3(faceN + (tangent2 * right + bitangent * bottom) * bumpmap_scale);
+            if (lightN.x != lightN.x) lightN = faceN;
+        }
+    }
+    v.faceN = faceN;
+    v.lightN = lightN;
+    v.g2l = rotation_between(lightN, mk3(0.f, 0.f, 1.f)); // SystemTransform(lightN, +Z), src/glm.hpp:21-24
+    v.VrL = qrot(v.g2l, v.Vr);
+}
+
+// Camera::GetCoordsFromDirection, reference src/camera.cpp:48-83 (Q16: coordinates clamped to the frame)
+__device__ inline bool coords_from_direction(const DevCamera& cam, f3 dir, int& x, int& y) {
+    const f3 N = mk3(cam.direction[0], cam.direction[1], cam.direction[2]);
+    const f3 origin = mk3(cam.origin[0], cam.origin[1], cam.origin[2]);
+    const f3 V = mk3(cam.viewscreen[0], cam.viewscreen[1], cam.viewscreen[2]);
+    const f3 v1 = mk3(cam.viewscreen_x[0], cam.viewscreen_x[1], cam.viewscreen_x[2]);
+    const f3 v2 = mk3(cam.viewscreen_y[0], cam.viewscreen_y[1], cam.viewscreen_y[2]);
+    float q = dot3(dir, N);
+    if ((double)q < 0.0001) return false;
+    float t = dot3(V - origin, N) / q;
+    if (t <= 0) return false;
+    f3 p = origin + dir * t;
+    f3 vp = p - V;
+    float plen = len3(vp);
+    float v1_cast_len = plen * (dot3(norm3(vp), norm3(v1)));
+    float v2_cast_len = plen * (dot3(norm3(vp), norm3(v2)));
+    float x_ratio = v1_cast_len / len3(v1);
+    float y_ratio = v2_cast_len / len3(v2);
+    if (x_ratio < 0.0f || x_ratio > 1.0f || y_ratio < 0.0f || y_ratio > 1.0f) return false;
+    x = (int)(cam.xsize * x_ratio);
+    y = (int)(cam.ysize * y_ratio);
+    if (x > cam.xsize - 1) x = cam.xsize - 1;
+    if (y > cam.ysize - 1) y = cam.ysize - 1;
+    return true;
+}

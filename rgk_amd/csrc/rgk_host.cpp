@@ -304,6 +304,8 @@ struct rgk_scene {
     // workspace
     size_t batch = 0;
     DevBuf<float4> rayA[2], rayB[2], hit, thr, tot, shA, shB, shC, pixsum, light;
+    DevBuf<float4> lstart, lv, term, vfin, vemit; // bidirectional state (reverse > 0)
+    uint32_t batch_reverse = 0;
     DevBuf<float> htab;
     DevBuf<float2> nearfar;
     DevBuf<uint32_t> counters, pix_xy, pix_seed;
@@ -321,7 +323,7 @@ struct rgk_scene {
         ltc_beckmann.release(); hdims.release(); hperm.release();
         for (int i = 0; i < 2; i++) { rayA[i].release(); rayB[i].release(); }
         hit.release(); thr.release(); tot.release(); shA.release(); shB.release(); shC.release(); pixsum.release();
-        light.release(); htab.release();
+        light.release(); htab.release(); lstart.release(); lv.release(); term.release(); vfin.release(); vemit.release();
         nearfar.release(); counters.release(); pix_xy.release(); pix_seed.release(); stats.release();
         scratch_f.release(); scratch_u.release();
         if (stream) (void)hipStreamDestroy(stream);
@@ -330,22 +332,32 @@ struct rgk_scene {
 
 namespace {
 
-int ensure_workspace(rgk_scene* s, size_t paths) {
-    if (paths <= s->batch) return 0;
+int ensure_workspace(rgk_scene* s, size_t paths, uint32_t reverse = 0) {
+    if (paths <= s->batch && reverse <= s->batch_reverse) return 0;
+    paths = std::max(paths, s->batch);
+    reverse = std::max(reverse, s->batch_reverse);
     int rc = 0;
     for (int i = 0; i < 2 && !rc; i++) { rc = s->rayA[i].alloc(paths); if (!rc) rc = s->rayB[i].alloc(paths); }
     if (!rc) rc = s->hit.alloc(paths);
     if (!rc) rc = s->thr.alloc(paths);
     if (!rc) rc = s->tot.alloc(paths);
-    if (!rc) rc = s->shA.alloc(paths);
-    if (!rc) rc = s->shB.alloc(paths);
-    if (!rc) rc = s->shC.alloc(paths);
+    if (!rc) rc = s->shA.alloc(paths * (reverse + 1)); // BDPT: 1 + reverse shadow rays per camera vertex
+    if (!rc) rc = s->shB.alloc(paths * (reverse + 1));
+    if (!rc) rc = s->shC.alloc(paths * (reverse + 1));
+    if (reverse) {
+        if (!rc) rc = s->lstart.alloc(paths);
+        if (!rc) rc = s->lv.alloc(paths * 4 * reverse);
+        if (!rc) rc = s->term.alloc(paths * (reverse + 1));
+        if (!rc) rc = s->vfin.alloc(paths);
+        if (!rc) rc = s->vemit.alloc(paths);
+    }
     if (!rc) rc = s->light.alloc(paths);
-    if (!rc) rc = s->counters.alloc(RGK_CNT_TOTAL);
+    if (!rc) rc = s->counters.alloc(2 * RGK_CNT_TOTAL); // [0]: camera phase, [1]: light sub-path phase
     if (!rc) rc = s->stats.alloc(8);
     if (rc) return rc;
-    if (!s->h_counters) HIPCHK(hipHostMalloc((void**)&s->h_counters, RGK_CNT_TOTAL * sizeof(uint32_t)));
+    if (!s->h_counters) HIPCHK(hipHostMalloc((void**)&s->h_counters, 2 * RGK_CNT_TOTAL * sizeof(uint32_t)));
     s->batch = paths;
+    s->batch_reverse = reverse;
     return 0;
 }
 
@@ -742,7 +754,7 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
     if (prm->xres == 0 || prm->yres == 0 || prm->xres > 65535 || prm->yres > 65535) return fail(RGK_ERR_INVALID, "resolution out of range");
     if (prm->multisample == 0) return fail(RGK_ERR_INVALID, "multisample must be >= 1");
     if (prm->depth > RGK_MAX_DEPTH) return fail(RGK_ERR_UNSUPPORTED, "recursion depth %u > %d", prm->depth, RGK_MAX_DEPTH);
-    if (prm->reverse != 0) return fail(RGK_ERR_UNSUPPORTED, "reverse (light sub-paths) is not implemented on the HIP path yet");
+    if (prm->reverse > 7) return fail(RGK_ERR_UNSUPPORTED, "reverse %u > 7 light sub-path vertices", prm->reverse);
     if (prm->sampler != RGK_SAMPLER_HALTON) return fail(RGK_ERR_UNSUPPORTED, "the HIP path implements the Halton sampler only");
     HIPCHK(hipSetDevice(s->device));
     if (counters) std::memset(counters, 0, sizeof(*counters));
@@ -766,7 +778,9 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
     const size_t B = batch_paths();
     const size_t npix_pass = std::min(P, B);
     const uint32_t ns_pass = (uint32_t)std::max<size_t>(1, std::min<size_t>(prm->multisample, B / npix_pass));
-    if ((rc = ensure_workspace(s, npix_pass * ns_pass))) return rc;
+    // no light at all: TracePath builds no light sub-path (`reverse > 0 && valid light`), same as reverse == 0
+    const uint32_t R = (s->dev.total_point_power + s->dev.total_areal_power > 0.0f) ? prm->reverse : 0u;
+    if ((rc = ensure_workspace(s, npix_pass * ns_pass, R))) return rc;
     if ((rc = s->pixsum.alloc(P))) return rc;
 
     DevCamera cam;
@@ -798,7 +812,9 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
     uint64_t path_rays = 0, shadow_rays = 0;
     PassParams pp{};
     pp.multisample = prm->multisample; pp.depth = prm->depth; pp.xres = prm->xres; pp.yres = prm->yres;
-    pp.clamp = prm->clamp; pp.russian = prm->russian; pp.bumpmap_scale = prm->bumpmap_scale; pp.reverse = prm->reverse;
+    pp.clamp = prm->clamp; pp.russian = prm->russian; pp.bumpmap_scale = prm->bumpmap_scale; pp.reverse = R;
+    pp.lstart = s->lstart.p; pp.lv = s->lv.p; pp.term = s->term.p; pp.vfin = s->vfin.p; pp.vemit = s->vemit.p;
+    pp.batch = (uint32_t)s->batch;
     pp.pix_xy = s->pix_xy.p; pp.pix_seed = s->pix_seed.p;
     if ((rc = s->htab.alloc((size_t)192 * prm->multisample))) return rc;
     TIMED(3, rgk_launch_build_halton_table(st, s->dev, prm->multisample, s->htab.p));
@@ -810,21 +826,51 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
             pp.s0 = s0;
             pp.ns = std::min(ns_pass, prm->multisample - s0);
             const uint32_t n0 = pp.npix * pp.ns;
-            TIMED(3, rgk_launch_init_counters(st, s->counters.p, n0));
-            TIMED(3, rgk_launch_raygen(st, s->dev, cam, pp, s->rayA[0].p, s->rayB[0].p, s->thr.p, s->tot.p));
-            for (uint32_t b = 0; b < prm->depth; b++) {
-                int q = b & 1;
-                TIMED(0, rgk_launch_trace_closest(st, s->dev, s->stack, count_stats, s->rayA[q].p, s->rayB[q].p, nullptr, s->hit.p,
-                                                  s->counters.p + RGK_CNT_QUEUE + b, s->counters.p + RGK_CNT_FETCH_T + b, s->stats.p));
-                TIMED(2, rgk_launch_shade(st, s->dev, cam, pp, b, s->rayA[q].p, s->rayB[q].p, s->hit.p, s->thr.p, s->tot.p,
-                                          s->rayA[q ^ 1].p, s->rayB[q ^ 1].p, s->shA.p, s->shB.p, s->shC.p, s->counters.p));
-                TIMED(1, rgk_launch_trace_shadow(st, s->dev, s->stack, count_stats, s->shA.p, s->shB.p, s->shC.p, s->tot.p, nullptr,
-                                                 s->counters.p + RGK_CNT_SHADOW + b, s->counters.p + RGK_CNT_FETCH_S + b, s->stats.p));
+            uint32_t* cn = s->counters.p;                   // camera-phase counters
+            uint32_t* cl = s->counters.p + RGK_CNT_TOTAL;   // light-phase counters
+            if (R == 0) {
+                TIMED(3, rgk_launch_init_counters(st, cn, n0));
+                TIMED(3, rgk_launch_raygen(st, s->dev, cam, pp, s->rayA[0].p, s->rayB[0].p, s->thr.p, s->tot.p));
+                for (uint32_t b = 0; b < prm->depth; b++) {
+                    int q = b & 1;
+                    TIMED(0, rgk_launch_trace_closest(st, s->dev, s->stack, count_stats, s->rayA[q].p, s->rayB[q].p, nullptr, s->hit.p,
+                                                      cn + RGK_CNT_QUEUE + b, cn + RGK_CNT_FETCH_T + b, s->stats.p));
+                    TIMED(2, rgk_launch_shade(st, s->dev, cam, pp, b, s->rayA[q].p, s->rayB[q].p, s->hit.p, s->thr.p, s->tot.p,
+                                              s->rayA[q ^ 1].p, s->rayB[q ^ 1].p, s->shA.p, s->shB.p, s->shC.p, cn));
+                    TIMED(1, rgk_launch_trace_shadow(st, s->dev, s->stack, count_stats, s->shA.p, s->shB.p, s->shC.p, s->tot.p, nullptr,
+                                                     RGK_SHADOW_ADD, nullptr, cn + RGK_CNT_SHADOW + b, cn + RGK_CNT_FETCH_S + b, s->stats.p));
+                }
+            } else {
+                // light sub-path first (its sampler dimensions are fixed), splats straight into the accumulator
+                TIMED(3, rgk_launch_init_counters(st, cl, n0));
+                TIMED(3, rgk_launch_raygen_light(st, s->dev, cam, pp, s->rayA[0].p, s->rayB[0].p, s->thr.p));
+                for (uint32_t k = 0; k < R; k++) {
+                    int q = k & 1;
+                    TIMED(0, rgk_launch_trace_closest(st, s->dev, s->stack, count_stats, s->rayA[q].p, s->rayB[q].p, nullptr, s->hit.p,
+                                                      cl + RGK_CNT_QUEUE + k, cl + RGK_CNT_FETCH_T + k, s->stats.p));
+                    TIMED(2, rgk_launch_shade_light(st, s->dev, cam, pp, k, s->rayA[q].p, s->rayB[q].p, s->hit.p, s->thr.p,
+                                                    s->rayA[q ^ 1].p, s->rayB[q ^ 1].p, s->shA.p, s->shB.p, s->shC.p, cl));
+                    TIMED(1, rgk_launch_trace_shadow(st, s->dev, s->stack, count_stats, s->shA.p, s->shB.p, s->shC.p, nullptr, nullptr,
+                                                     RGK_SHADOW_SPLAT, d_accum_rgb, cl + RGK_CNT_SHADOW + k, cl + RGK_CNT_FETCH_S + k, s->stats.p));
+                }
+                TIMED(3, rgk_launch_init_counters(st, cn, n0));
+                TIMED(3, rgk_launch_raygen_camera(st, s->dev, cam, pp, s->rayA[0].p, s->rayB[0].p, s->thr.p, s->tot.p));
+                for (uint32_t b = 0; b < prm->depth; b++) {
+                    int q = b & 1;
+                    TIMED(0, rgk_launch_trace_closest(st, s->dev, s->stack, count_stats, s->rayA[q].p, s->rayB[q].p, nullptr, s->hit.p,
+                                                      cn + RGK_CNT_QUEUE + b, cn + RGK_CNT_FETCH_T + b, s->stats.p));
+                    TIMED(2, rgk_launch_shade_bdpt(st, s->dev, cam, pp, b, s->rayA[q].p, s->rayB[q].p, s->hit.p, s->thr.p, s->tot.p,
+                                                   s->rayA[q ^ 1].p, s->rayB[q ^ 1].p, s->shA.p, s->shB.p, s->shC.p, cn));
+                    TIMED(1, rgk_launch_trace_shadow(st, s->dev, s->stack, count_stats, s->shA.p, s->shB.p, s->shC.p, s->term.p, nullptr,
+                                                     RGK_SHADOW_CELL, nullptr, cn + RGK_CNT_SHADOW + b, cn + RGK_CNT_FETCH_S + b, s->stats.p));
+                    TIMED(3, rgk_launch_finish_vertex(st, pp, b, s->rayB[q].p, s->tot.p, cn));
+                }
             }
             TIMED(3, rgk_launch_resolve(st, pp, s->tot.p, s->pixsum.p, d_accum_rgb, d_accum_count));
-            HIPCHK(hipMemcpyAsync(s->h_counters, s->counters.p, RGK_CNT_TOTAL * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(s->h_counters, s->counters.p, 2 * RGK_CNT_TOTAL * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
             for (uint32_t b = 0; b < prm->depth; b++) { path_rays += s->h_counters[RGK_CNT_QUEUE + b]; shadow_rays += s->h_counters[RGK_CNT_SHADOW + b]; }
+            for (uint32_t k = 0; k < R; k++) { path_rays += s->h_counters[RGK_CNT_TOTAL + RGK_CNT_QUEUE + k]; shadow_rays += s->h_counters[RGK_CNT_TOTAL + RGK_CNT_SHADOW + k]; }
         }
     }
     HIPCHK(hipGetLastError());
@@ -921,7 +967,7 @@ int rgk_trace_visibility(rgk_scene* s, uint32_t n, const float* a, const float* 
     rgk_launch_init_counters(st, s->counters.p, n);
     rgk_launch_pack_visibility(st, s->dev, n, s->scratch_f.p, s->scratch_f.p + (size_t)3 * n, s->shA.p, s->shB.p, s->shC.p);
     rgk_launch_trace_shadow(st, s->dev, s->stack, counters != nullptr, s->shA.p, s->shB.p, s->shC.p, s->tot.p, (uint8_t*)s->scratch_u.p,
-                            s->counters.p + RGK_CNT_QUEUE, s->counters.p + RGK_CNT_FETCH_S, s->stats.p);
+                            RGK_SHADOW_ADD, nullptr, s->counters.p + RGK_CNT_QUEUE, s->counters.p + RGK_CNT_FETCH_S, s->stats.p);
     HIPCHK(hipMemcpyAsync(visible, s->scratch_u.p, n, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());

@@ -14,6 +14,11 @@
 #define RGK_CNT_FETCH_S 192 // [b]  work-fetch cursor of k_trace_shadow at bounce b
 #define RGK_CNT_TOTAL 256
 
+// what k_trace_shadow does with a visible ray's payload
+#define RGK_SHADOW_ADD 0   // tot[slot] += radiance                     (uni-directional path)
+#define RGK_SHADOW_CELL 1  // cells[target] = radiance                  (BDPT: term[q][slot])
+#define RGK_SHADOW_SPLAT 2 // atomicAdd(accum_rgb[pixel], radiance)     (BDPT: light-tracing side effect)
+
 // One pass = pixels [j0, j0+npix) of the round's pixel list x samples [s0, s0+ns).
 // Path slot = (s - s0) * npix + (j - j0).
 struct PassParams {
@@ -25,6 +30,13 @@ struct PassParams {
     const uint32_t* pix_seed; // PathTracer::samplerSeed for that pixel (a2)
     const float* htab;        // halton_raw(hdim, s) for hdim < 192, s < multisample: htab[hdim * multisample + s]
     float4* light;            // per slot: the path's light {pos.xyz, code}, written by k_raygen
+    // bidirectional state (reverse > 0), null otherwise; per slot with stride `batch`
+    float4* lstart;           // light_at_path_start.rgb
+    float4* lv;               // light vertices: lv[(k*4 + c) * batch + slot], c: {pos,mat}{lightN,u}{Vr,v}{light_from_source,valid}
+    float4* term;             // term[q * batch + slot]: q = 0 NEE, q = 1..reverse connections
+    float4* vfin;             // {contribution.rgb, 1 if the slot has a vertex awaiting k_finish_vertex}
+    float4* vemit;            // emission of that vertex if front-facing
+    uint32_t batch;
 };
 
 void rgk_launch_init_counters(hipStream_t st, uint32_t* counters, uint32_t n0);
@@ -34,8 +46,19 @@ void rgk_launch_raygen(hipStream_t st, const DevScene& sc, const DevCamera& cam,
 void rgk_launch_trace_closest(hipStream_t st, const DevScene& sc, int stack, bool count_stats, const float4* rayA, const float4* rayB,
                               const float2* nearfar, float4* hit, const uint32_t* count_ptr, uint32_t* fetch, unsigned long long* stats);
 void rgk_launch_trace_shadow(hipStream_t st, const DevScene& sc, int stack, bool count_stats, const float4* shA, const float4* shB,
-                             const float4* shC, float4* tot, uint8_t* vis_out, const uint32_t* count_ptr, uint32_t* fetch,
-                             unsigned long long* stats);
+                             const float4* shC, float4* tot, uint8_t* vis_out, int mode, float* splat_rgb, const uint32_t* count_ptr,
+                             uint32_t* fetch, unsigned long long* stats);
+void rgk_launch_raygen_light(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, float4* rayA, float4* rayB,
+                             float4* thr);
+void rgk_launch_raygen_camera(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, float4* rayA, float4* rayB,
+                              float4* thr, float4* tot);
+void rgk_launch_shade_light(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t k, const float4* rayA,
+                            const float4* rayB, const float4* hit, float4* thr, float4* nextA, float4* nextB, float4* shA, float4* shB,
+                            float4* shC, uint32_t* counters);
+void rgk_launch_shade_bdpt(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t bounce,
+                           const float4* rayA, const float4* rayB, const float4* hit, float4* thr, float4* tot, float4* nextA, float4* nextB,
+                           float4* shA, float4* shB, float4* shC, uint32_t* counters);
+void rgk_launch_finish_vertex(hipStream_t st, const PassParams& pp, uint32_t bounce, const float4* rayB, float4* tot, const uint32_t* counters);
 void rgk_launch_shade(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t bounce, const float4* rayA,
                       const float4* rayB, const float4* hit, float4* thr, float4* tot, float4* nextA, float4* nextB, float4* shA,
                       float4* shB, float4* shC, uint32_t* counters);

@@ -62,7 +62,6 @@ __global__ __launch_bounds__(256) void k_raygen(const DevScene sc, const DevCame
 }
 
 // ------------------------------------------------------------------ K3+K4+K6+K7: shade
-__device__ __forceinline__ f3 clamp3(f3 v, float c) { return mk3(v.x > c ? c : v.x, v.y > c ? c : v.y, v.z > c ? c : v.z); }
 
 __global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade(const DevScene sc, const DevCamera cam, const PassParams pp, const uint32_t bounce,
                                                             const float4* __restrict__ rayA, const float4* __restrict__ rayB,
@@ -251,6 +250,8 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade(const DevScene sc,
     }
 }
 
+#include "rgk_bdpt.h" // K8: light sub-path, splats, connections (reverse > 0)
+
 // ------------------------------------------------------------------ K9: resolve
 // final clamp + NaN/negative scrub (path_tracer.cpp:502-507), per-pixel sum over the pass's
 // samples in sample order (RenderPixel :64), then AddPixel when the pixel's last sample is in.
@@ -362,10 +363,10 @@ void rgk_launch_trace_closest(hipStream_t st, const DevScene& sc, int stack, boo
 }
 
 void rgk_launch_trace_shadow(hipStream_t st, const DevScene& sc, int stack, bool count_stats, const float4* shA, const float4* shB,
-                             const float4* shC, float4* tot, uint8_t* vis_out, const uint32_t* count_ptr, uint32_t* fetch,
-                             unsigned long long* stats) {
+                             const float4* shC, float4* tot, uint8_t* vis_out, int mode, float* splat_rgb, const uint32_t* count_ptr,
+                             uint32_t* fetch, unsigned long long* stats) {
     int grid = trace_grid(stack);
-#define L(C, S) k_trace_shadow<C, S><<<grid, RGK_TRACE_BLOCK, 0, st>>>(sc, shA, shB, shC, tot, vis_out, count_ptr, fetch, stats)
+#define L(C, S) k_trace_shadow<C, S><<<grid, RGK_TRACE_BLOCK, 0, st>>>(sc, shA, shB, shC, tot, vis_out, mode, splat_rgb, count_ptr, fetch, stats)
     if (stack <= 32) { if (count_stats) L(true, 32); else L(false, 32); }
     else { if (count_stats) L(true, 64); else L(false, 64); }
 #undef L
@@ -393,4 +394,31 @@ void rgk_launch_unpack_hits(hipStream_t st, uint32_t n, const float4* hit, rgk_h
 void rgk_launch_sampler_eval(hipStream_t st, const DevScene& sc, uint32_t n, const uint32_t* seed, const uint32_t* index, const uint32_t* dim,
                              int is2d, float* out) {
     k_sampler_eval<<<(n + 255) / 256, 256, 0, st>>>(sc, n, seed, index, dim, is2d, out);
+}
+
+static inline int slot_grid(const PassParams& pp) {
+    uint32_t n = pp.npix * pp.ns;
+    int grid = (int)((n + 255) / 256);
+    return grid > 256 * 16 ? 256 * 16 : grid;
+}
+void rgk_launch_raygen_light(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, float4* rayA, float4* rayB,
+                             float4* thr) {
+    k_raygen_light<<<slot_grid(pp), 256, 0, st>>>(sc, cam, pp, rayA, rayB, thr);
+}
+void rgk_launch_raygen_camera(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, float4* rayA, float4* rayB,
+                              float4* thr, float4* tot) {
+    k_raygen_camera<<<slot_grid(pp), 256, 0, st>>>(sc, cam, pp, rayA, rayB, thr, tot);
+}
+void rgk_launch_shade_light(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t k, const float4* rayA,
+                            const float4* rayB, const float4* hit, float4* thr, float4* nextA, float4* nextB, float4* shA, float4* shB,
+                            float4* shC, uint32_t* counters) {
+    k_shade_light<<<256 * 4, RGK_SHADE_BLOCK, 0, st>>>(sc, cam, pp, k, rayA, rayB, hit, thr, nextA, nextB, shA, shB, shC, counters);
+}
+void rgk_launch_shade_bdpt(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t bounce,
+                           const float4* rayA, const float4* rayB, const float4* hit, float4* thr, float4* tot, float4* nextA, float4* nextB,
+                           float4* shA, float4* shB, float4* shC, uint32_t* counters) {
+    k_shade_bdpt<<<256 * 4, RGK_SHADE_BLOCK, 0, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
+}
+void rgk_launch_finish_vertex(hipStream_t st, const PassParams& pp, uint32_t bounce, const float4* rayB, float4* tot, const uint32_t* counters) {
+    k_finish_vertex<<<256 * 8, 256, 0, st>>>(pp, bounce, rayB, tot, counters);
 }

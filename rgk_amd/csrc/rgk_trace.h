@@ -82,6 +82,7 @@ template <bool ANY, bool COUNT, int STACK>
 __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float4* __restrict__ q0, const float4* __restrict__ q1,
                                                  const float4* __restrict__ q2, const float2* __restrict__ nearfar,
                                                  float4* __restrict__ hit, float4* __restrict__ tot, uint8_t* __restrict__ vis_out,
+                                                 const int mode, float* __restrict__ splat_rgb,
                                                  const uint32_t count, uint32_t* __restrict__ fetch, int* __restrict__ stack,
                                                  uint32_t& n_nodes, uint32_t& n_tris) {
     const int lane = threadIdx.x & 63;
@@ -237,9 +238,17 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
             if (!ANY) hit[idx] = make_float4(best_t, best_a, best_b, __int_as_float(best_tri));
             else if (vis_out) vis_out[idx] = best_tri < 0;
             else if (best_tri < 0) {
-                float4 t = tot[slot]; // one path per slot, one shadow ray per path and bounce: no race
-                t.x = t.x + rad.x; t.y = t.y + rad.y; t.z = t.z + rad.z;
-                tot[slot] = t;
+                if (mode == RGK_SHADOW_ADD) {
+                    float4 t = tot[slot]; // one path per slot, one shadow ray per path and bounce: no race
+                    t.x = t.x + rad.x; t.y = t.y + rad.y; t.z = t.z + rad.z;
+                    tot[slot] = t;
+                } else if (mode == RGK_SHADOW_CELL) {
+                    tot[slot] = make_float4(rad.x, rad.y, rad.z, 0.f); // `slot` = term cell, owned by this ray alone
+                } else { // RGK_SHADOW_SPLAT: light-tracing side effect, AddPixel(x2, y2, r, 0) tracer.cpp:20-26; `slot` = pixel
+                    atomicAdd(&splat_rgb[3 * (size_t)slot + 0], rad.x);
+                    atomicAdd(&splat_rgb[3 * (size_t)slot + 1], rad.y);
+                    atomicAdd(&splat_rgb[3 * (size_t)slot + 2], rad.z);
+                }
             }
             active = false;
         }
@@ -254,7 +263,7 @@ __global__ __launch_bounds__(RGK_TRACE_BLOCK) void k_trace_closest(const DevScen
                                                                     uint32_t* __restrict__ fetch, unsigned long long* __restrict__ stats) {
     __shared__ int lds_stack[STACK * RGK_TRACE_BLOCK];
     uint32_t n_nodes = 0, n_tris = 0;
-    trace_persistent<false, COUNT, STACK>(sc, rayA, rayB, nullptr, nearfar, hit, nullptr, nullptr, *count_ptr, fetch,
+    trace_persistent<false, COUNT, STACK>(sc, rayA, rayB, nullptr, nearfar, hit, nullptr, nullptr, 0, nullptr, *count_ptr, fetch,
                                           lds_stack + threadIdx.x, n_nodes, n_tris);
     if (COUNT) {
         atomicAdd(&stats[0], (unsigned long long)n_nodes);
@@ -268,11 +277,12 @@ template <bool COUNT, int STACK>
 __global__ __launch_bounds__(RGK_TRACE_BLOCK) void k_trace_shadow(const DevScene sc, const float4* __restrict__ shA,
                                                                    const float4* __restrict__ shB, const float4* __restrict__ shC,
                                                                    float4* __restrict__ tot, uint8_t* __restrict__ vis_out,
+                                                                   const int mode, float* __restrict__ splat_rgb,
                                                                    const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ fetch,
                                                                    unsigned long long* __restrict__ stats) {
     __shared__ int lds_stack[STACK * RGK_TRACE_BLOCK];
     uint32_t n_nodes = 0, n_tris = 0;
-    trace_persistent<true, COUNT, STACK>(sc, shA, shB, shC, nullptr, nullptr, tot, vis_out, *count_ptr, fetch,
+    trace_persistent<true, COUNT, STACK>(sc, shA, shB, shC, nullptr, nullptr, tot, vis_out, mode, splat_rgb, *count_ptr, fetch,
                                          lds_stack + threadIdx.x, n_nodes, n_tris);
     if (COUNT) {
         atomicAdd(&stats[2], (unsigned long long)n_nodes);

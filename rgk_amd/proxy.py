@@ -243,17 +243,23 @@ def icosphere(mesh, centre, radius, level, uvscale=1.0):
 
 
 # ----------------------------------------------------------------------- the scene
-def install_sponza_materials(sb):
-    texcache = {}
+def proxy_texture(sb, name):
+    """The procedural stand-in for one of the shipped Sponza JPGs (by file name), or -1."""
+    import os
+    name = os.path.basename(name) if name else name
+    if name is None or name not in SPONZA_TEX_DIMS:
+        return -1
+    key = "proxy:" + name
+    if key not in sb.tex_by_path:
+        w, h = SPONZA_TEX_DIMS[name]
+        img = procedural_texture(name, w, h)[::-1]  # JPEGs are stored flipped (Q12)
+        sb.add_image_texture(key, gamma_decode_u8(np.ascontiguousarray(img)))
+    return sb.tex_by_path[key]
 
+
+def install_sponza_materials(sb):
     def tex(name):
-        if name is None:
-            return -1
-        if name not in texcache:
-            w, h = SPONZA_TEX_DIMS[name]
-            img = procedural_texture(name, w, h)[::-1]  # JPEGs are stored flipped (Q12)
-            texcache[name] = sb.add_image_texture("proxy:" + name, gamma_decode_u8(np.ascontiguousarray(img)))
-        return texcache[name]
+        return proxy_texture(sb, name)
 
     for name, (ns, kd, ks, mkd, mbump) in SPONZA_MTL.items():
         mtl = dict(Ns=ns, Kd=kd, Ks=ks, map_Kd=mkd, map_Bump=mbump)
@@ -334,10 +340,36 @@ def sponza_proxy(sb, detail=1.0):
     return total
 
 
-def sponza_mesh_provider(detail=1.0):
-    """For Config.build_scene(mesh_provider=...): substitutes the proxy for sponza.obj."""
+def dragon_proxy(sb, level=7):
+    """Stand-in for dragon.obj's statue: three noise-displaced icospheres on a plinth,
+    3 * 20 * 4^level triangles (level 7: 983 k ~ the Stanford dragon's 871 k), one glossy material."""
+    mtl = dict(Ns=100.0, Kd=(0.60, 0.55, 0.30), Ks=(0.40, 0.38, 0.30), map_Kd=None, map_Bump=None)
+    sb.register_material(sb.material_from_mtl("dragon", mtl, ""), False)
+    rng = np.random.default_rng(871414)
+    m = Mesh()
+    for (c, r) in (((0.35, 1.55, 0.15), 0.55), ((0.95, 2.05, 0.25), 0.33), ((-0.25, 1.25, -0.1), 0.38)):
+        icosphere(m, c, r, level)
+        p = m.p[-1]
+        v = (p - np.asarray(c, dtype=f32)) / f32(r)
+        k = rng.uniform(2.0, 5.0, (3, 3))
+        bump = sum(np.sin(v @ k[i] * (i + 2) + i) for i in range(3)) / 3.0
+        m.p[-1] = (np.asarray(c, dtype=f32) + v * (r * (1.0 + 0.12 * bump[:, None]))).astype(f32)
+    m.emit(sb, "dragon")
+    plinth = Mesh()
+    box(plinth, (-0.6, 0.0, -0.9), (1.5, 0.7, 1.0), 4)
+    plinth.emit(sb, "sp_01_stub_baza")
+    return m.ntris() + plinth.ntris()
+
+
+def sponza_mesh_provider(detail=1.0, dragon_level=7):
+    """For Config.build_scene(mesh_provider=...): substitutes the proxies for sponza.obj / dragon.obj."""
     def provide(sb, rel, T=None, forced=""):
-        if "sponza" not in rel:
+        if "sponza" not in rel and "dragon" not in rel:
             raise FileNotFoundError(rel)
+        had = dict(sb.mat_by_name)  # JSON materials registered first win (import-materials without override)
         sponza_proxy(sb, detail)
+        if "dragon" in rel:
+            dragon_proxy(sb, dragon_level)
+        for name, idx in had.items():
+            sb.mat_by_name[name] = sb.mat_by_name.get(name, idx)
     return provide

@@ -165,6 +165,7 @@ class SceneBuilder:
         self.areal = []          # list of triangle-id lists
         self.sky = dict(mode=capi.SKY_COLOR, color=(0.0, 0.0, 0.0), intensity=1.0, rotate=0.0, tex=-1)
         self.geometry_label = "real"
+        self.texture_fallback = None
         self._keep = []
 
     # ---- textures -------------------------------------------------------------
@@ -191,6 +192,10 @@ class SceneBuilder:
         try:
             return self.add_image_texture(key, load_texture_file(path))
         except Exception as e:  # "Failed to load texture ..., ignoring it."
+            if self.texture_fallback is not None:  # labelled proxy assets (rgk_amd.proxy)
+                t = self.texture_fallback(self, path)
+                if t >= 0:
+                    return t
             print(f"Failed to load texture '{path}' ({e}), ignoring it.")
             return -1
 

@@ -196,6 +196,18 @@ def test_sponza4_sphere_light_clamp_russian(rd, oracle):
     assert img.max() <= wl.clamp * (1 + 1e-6)
 
 
+def test_dragon_sponza_config4_small(rd, oracle):
+    """BASELINE configs[3] at small size: sphere light, reverse = 3, depth 40, clamp 5, russian 0.7, JSON
+    material override (exponent 800 LTC) over the proxy geometry + statue stand-in."""
+    from rgk_amd.workloads import Workload
+    wl = Workload("dragon-sponza-1080p", scale=0.05, spp=8, dragon_level=3)
+    assert wl.reverse == 3 and wl.depth == 40
+    img, ref, kg, ko = render_both(rd, oracle, wl)
+    rel, within = image_metrics(img, ref, wl.clamp, wl.multisample)
+    assert rel <= 3e-2 and within >= 0.97, (rel, within)
+    assert abs(int(kg.path_rays) - int(ko.path_rays)) <= 2e-3 * ko.path_rays
+
+
 def material_zoo():
     """Cornell-like box exercising mirror, dielectric, transparent, mix, ltc_beckmann, no-russian, thin lens."""
     sb = SceneBuilder()
@@ -249,6 +261,41 @@ def test_material_zoo_image_parity(rd, oracle):
         # delta BxDFs + sin/cos ulp differences flip a few paths: outlier budget 1 %
         assert rel <= 2e-2 and within >= 0.99, (lens, rel, within)
         assert abs(int(kg.path_rays) - int(ko.path_rays)) <= 2e-3 * ko.path_rays
+
+
+def test_bidirectional_reverse_parity(rd, oracle):
+    """reverse > 0 (BASELINE configs[3] feature): light sub-path, light-tracing splats (count 0, may land on
+    any pixel), connections of every camera vertex to every light vertex (path_tracer.cpp:336-398,463-480)."""
+    from rgk_amd.workloads import Workload
+    wl = Workload("cornell-256", scale=0.25, spp=16)
+    g, o = both(rd, oracle, wl)
+    for reverse, depth in ((1, 3), (3, 5)):
+        prm = make_params(wl.xres, wl.yres, wl.multisample, depth, clamp=20.0, russian=0.7, reverse=reverse)
+        ag, cg, kg = g.render_round(wl.camera, prm, rd.generate_task_list(wl.xres, wl.yres))
+        ao, co, ko = o.render_round(wl.camera, prm, oracle.generate_task_list(wl.xres, wl.yres))
+        assert np.array_equal(cg, co)                               # splats add radiance with count 0
+        rel = np.linalg.norm(ag - ao) / np.linalg.norm(ao)
+        assert rel <= 2e-3, (reverse, rel)                          # float atomics reorder the splat sums
+        assert abs(int(kg.path_rays) - int(ko.path_rays)) <= 1e-3 * ko.path_rays   # camera + light sub-path rays
+    # zoo: delta + LTC materials on both sub-paths, thin lens (camera position per sample)
+    sb = material_zoo()
+    desc = sb.to_desc()
+    g2, o2 = rd.Scene(desc), oracle.OracleScene(desc)
+    W, H, S = 64, 48, 32
+    cam = make_camera((0, 1.5, 5.5), (0, 1.3, 0), (0, 1, 0), fov=45, xres=W, yres=H, focus_plane=5.0, lens_size=0.05)
+    prm = make_params(W, H, S, 6, clamp=30.0, russian=0.7, reverse=2)
+    ag, cg, kg = g2.render_round(cam, prm, rd.generate_task_list(W, H))
+    ao, co, ko = o2.render_round(cam, prm, oracle.generate_task_list(W, H))
+    assert np.array_equal(cg, co)
+    assert np.linalg.norm(ag - ao) / np.linalg.norm(ao) <= 3e-2
+    # no lights at all: reverse has no effect (no light sub-path is built)
+    sb0 = SceneBuilder(); m = sb0.new_material("m", capi.BXDF_DIFFUSE); m["tex_diffuse"] = sb0.create_solid_texture((0.5, 0.5, 0.5))
+    sb0.register_material(m); sb0.add_primitive("cube", np.eye(4, dtype=np.float32), "m"); sb0.set_skybox_color((0.5, 0.6, 0.7), 1.0)
+    g3 = rd.Scene(sb0.to_desc())
+    cam3 = make_camera((0, 0.3, 3), (0, 0, 0), (0, 1, 0), fov=40, xres=32, yres=32)
+    a0 = g3.render_round(cam3, make_params(32, 32, 4, 3, reverse=0), rd.generate_task_list(32, 32))[0]
+    a2 = g3.render_round(cam3, make_params(32, 32, 4, 3, reverse=2), rd.generate_task_list(32, 32))[0]
+    assert np.array_equal(a0, a2)
 
 
 # ----------------------------------------------------------------------- boundary behaviour, properties
@@ -319,8 +366,10 @@ def test_error_codes(rd, product_lib, cornell):
     bad = (capi.Tile * 1)(); bad[0].x0, bad[0].x1, bad[0].y0, bad[0].y1 = 0, cornell.xres + 5, 0, 8
     assert product_lib.rgk_render_round(g.h, C.byref(cornell.camera), C.byref(prm), bad, 1, acc.ctypes.data, cnt.ctypes.data, None) == -1
     assert b"outside the frame" in product_lib.rgk_last_error()
-    p2 = cornell.params(); p2.reverse = 3
+    p2 = cornell.params(); p2.reverse = 9          # more light-path vertices than the kernels keep per slot
     assert product_lib.rgk_render_round(g.h, C.byref(cornell.camera), C.byref(p2), tiles, len(tiles), acc.ctypes.data, cnt.ctypes.data, None) == -5
+    p2b = cornell.params(); p2b.sampler = capi.SAMPLER_STRATIFIED   # mt19937 tables: oracle only
+    assert product_lib.rgk_render_round(g.h, C.byref(cornell.camera), C.byref(p2b), tiles, len(tiles), acc.ctypes.data, cnt.ctypes.data, None) == -5
     p3 = cornell.params(); p3.multisample = 0
     assert product_lib.rgk_render_round(g.h, C.byref(cornell.camera), C.byref(p3), tiles, len(tiles), acc.ctypes.data, cnt.ctypes.data, None) == -1
     assert not acc.any()
