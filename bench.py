@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + RGK_FORCE_DEVICE=0 rehearses N ranks on one GPU")
     args = ap.parse_args()
 
     import numpy as np
@@ -78,12 +79,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if os.environ.get("RGK_FORCE_DEVICE") is not None:  # rehearsal: several ranks share one card
+        local_rank = int(os.environ["RGK_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=args.backend)
 
     wl = Workload(args.workload, scale=args.scale, spp=args.spp)
     base_spp = wl.multisample
@@ -99,7 +105,8 @@ def main():
         def get_params(sampler=capi.SAMPLER_HALTON, flags=0):
             return wl.params(sampler, flags)
 
-    drv = rd.RenderDriver(scene, Cfg, wl.camera, rank=rank, world_size=world, device=device, flags=capi.FLAG_TIME_KERNELS)
+    drv = rd.RenderDriver(scene, Cfg, wl.camera, rank=rank, world_size=world, device=device, flags=capi.FLAG_TIME_KERNELS,
+                          host_reduce=(args.backend != "nccl"))
 
     def barrier():
         if world > 1:
@@ -113,15 +120,16 @@ def main():
     cnts = [drv.render_round() for _ in range(args.steps)]
     barrier()
     elapsed = time.perf_counter() - t0
+    cdev = device if args.backend == "nccl" else torch.device("cpu")
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # whole-job unit counts (all ranks)
     local = np.array([sum(c.paths for c in cnts), sum(c.path_rays for c in cnts), sum(c.shadow_rays for c in cnts)], dtype=np.float64)
     if world > 1:
-        t = torch.tensor(local, dtype=torch.float64, device=device)
+        t = torch.tensor(local, dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         tot = t.cpu().numpy()
     else:
@@ -133,7 +141,8 @@ def main():
     ms_trace = sum(c.ms_trace for c in cnts)
     n_launch = sum(c.n_trace_launches for c in cnts)
     rays_local = sum(c.path_rays for c in cnts)
-    drv_c = rd.RenderDriver(scene, Cfg, wl.camera, rank=rank, world_size=world, device=device, flags=capi.FLAG_COUNT_TRAVERSAL)
+    drv_c = rd.RenderDriver(scene, Cfg, wl.camera, rank=rank, world_size=world, device=device, flags=capi.FLAG_COUNT_TRAVERSAL,
+                            host_reduce=(args.backend != "nccl"))
     cc = drv_c.render_round(reduce=False)
     nodes_per_ray = cc.node_visits / max(1, cc.path_rays)
     tris_per_ray = cc.tri_tests / max(1, cc.path_rays)
@@ -141,8 +150,22 @@ def main():
     bytes_per_ray = 32 + 4 + 16 + nodes_per_ray * info.node_bytes + tris_per_ray * info.tri_bytes
     alg_bytes = bytes_per_ray * rays_local
     achieved = alg_bytes / (ms_trace * 1e-3) / 1e9 if ms_trace > 0 else 0.0
+    # physical HBM-side traffic per launch of that kernel: FETCH_SIZE (x2, gfx950) + WRITE_SIZE from the committed
+    # rocprofv3 --pmc passes of this same command (profiles/<round>_hbm_traffic.csv); bench.py cannot run the
+    # profiler on itself, so the value is only attached when workload and batch match the profiled run
+    traffic = None
+    try:
+        import csv
+        if args.workload == "sponza-1080p" and args.scale == 1.0 and args.spp is None and world == 1:
+            prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_hbm_traffic.csv"))[-1]
+            for row in csv.DictReader(open(os.path.join(ROOT, "profiles", prof))):
+                if row["kernel"].startswith("k_trace_closest<false"):
+                    traffic = float(row["hbm_MB_per_launch"]) * 1e6
+    except Exception:
+        traffic = None
     roofline = {"bound": "hbm", "kernel": "k_trace_closest", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 4), "traffic": None,
+                "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                "alg_bytes_per_launch": round(alg_bytes / max(1, n_launch), 1),
                 "launches": n_launch, "avg_launch_ms": round(ms_trace / max(1, n_launch), 4),
                 "alg_bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(nodes_per_ray, 2),
                 "tris_per_ray": round(tris_per_ray, 2), "node_bytes": info.node_bytes, "tri_bytes": info.tri_bytes,

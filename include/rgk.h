@@ -64,16 +64,23 @@ typedef struct rgk_material {
 
 /* ---- textures: ReadableTexture family, src/texture.hpp:10-80 ---- */
 typedef enum rgk_texture_kind {
-    RGK_TEX_SOLID = 0, /* SolidTexture: constant colour, slopes 0 */
-    RGK_TEX_RGB32F = 1 /* FileTexture: width*height Color{r,g,b} float triples, row-major,
-                          already gamma-decoded / flipped as the reference loader does */
+    RGK_TEX_SOLID = 0,  /* SolidTexture: constant colour, slopes 0 */
+    RGK_TEX_RGB32F = 1, /* FileTexture: width*height Color{r,g,b} float triples, row-major,
+                           already gamma-decoded / flipped as the reference loader does */
+    RGK_TEX_RGB8 = 2    /* FileTexture decoded from an 8-bit file (PNG/JPEG, src/texture.cpp:189-292):
+                           the bytes as stored (row-major, flipped as the loader does) plus the 256-entry
+                           table that turns a byte into the float the reference would hold
+                           (Color(byte/255).gammaDecode(2.2)).  Same texel values as RGK_TEX_RGB32F at a
+                           quarter of the memory traffic. */
 } rgk_texture_kind;
 
 typedef struct rgk_texture {
     uint32_t kind;
     uint32_t width, height;
-    float color[3];      /* RGK_TEX_SOLID */
-    const float *texels; /* RGK_TEX_RGB32F: 3*width*height floats */
+    float color[3];         /* RGK_TEX_SOLID */
+    const float *texels;    /* RGK_TEX_RGB32F: 3*width*height floats */
+    const uint8_t *texels8; /* RGK_TEX_RGB8: 3*width*height bytes */
+    const float *lut;       /* RGK_TEX_RGB8: 256 floats, byte -> channel value */
 } rgk_texture;
 
 /* ---- point / sphere lights: Light{FULL_SPHERE}, src/primitives.hpp:26-43,

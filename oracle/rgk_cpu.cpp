@@ -103,7 +103,12 @@ struct Texture {
     uint32_t xsize = 0, ysize = 0;
     Color color;
     const float* data = nullptr; // 3 floats per texel, owned by Scene::texel_store
-    Color texel(int idx) const { return Color(data[3 * idx], data[3 * idx + 1], data[3 * idx + 2]); }
+    const uint8_t* data8 = nullptr; // RGK_TEX_RGB8: 3 bytes per texel + byte -> float table
+    const float* lut = nullptr;
+    Color texel(int idx) const {
+        if (kind == RGK_TEX_RGB8) return Color(lut[data8[3 * idx]], lut[data8[3 * idx + 1]], lut[data8[3 * idx + 2]]);
+        return Color(data[3 * idx], data[3 * idx + 1], data[3 * idx + 2]);
+    }
     // texture.cpp:35-77 (FileTexture) / texture.hpp:64-80 (SolidTexture)
     Color GetPixelInterpolated(vec2 pos) const {
         if (kind == RGK_TEX_SOLID) return color;
@@ -230,6 +235,7 @@ struct Scene {
     std::vector<Material> materials;
     std::vector<Texture> textures;
     std::vector<std::vector<float>> texel_store;
+    std::vector<std::vector<uint8_t>> texel8_store;
     std::vector<Light> pointlights;
     std::vector<std::pair<float, ArealLight>> areal_lights;
     float total_areal_power = 0, total_point_power = 0;
@@ -1363,6 +1369,7 @@ void* orc_scene_create(const rgk_scene_desc* d) {
     }
     s->textures.resize(d->n_textures);
     s->texel_store.resize(d->n_textures);
+    s->texel8_store.resize(d->n_textures);
     for (uint32_t i = 0; i < d->n_textures; i++) {
         const rgk_texture& t = d->textures[i];
         Texture& o = s->textures[i];
@@ -1371,6 +1378,11 @@ void* orc_scene_create(const rgk_scene_desc* d) {
         if (t.kind == RGK_TEX_RGB32F) {
             s->texel_store[i].assign(t.texels, t.texels + (size_t)3 * t.width * t.height);
             o.data = s->texel_store[i].data();
+        } else if (t.kind == RGK_TEX_RGB8) {
+            s->texel8_store[i].assign(t.texels8, t.texels8 + (size_t)3 * t.width * t.height);
+            s->texel_store[i].assign(t.lut, t.lut + 256);
+            o.data8 = s->texel8_store[i].data();
+            o.lut = s->texel_store[i].data();
         }
     }
     s->materials.resize(d->n_materials);

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(HERE, "csrc", "librgk_hip.so")
 BXDF_DIFFUSE, BXDF_MIRROR, BXDF_DIELECTRIC, BXDF_TRANSPARENT, BXDF_MIX = 0, 1, 2, 3, 4
 BXDF_LTC_BECKMANN, BXDF_LTC_GGX, BXDF_LTC_BECKMANN_DIFFUSE, BXDF_LTC_GGX_DIFFUSE = 5, 6, 7, 8
 MAT_NO_RUSSIAN = 1
-TEX_SOLID, TEX_RGB32F = 0, 1
+TEX_SOLID, TEX_RGB32F, TEX_RGB8 = 0, 1, 2
 SKY_COLOR, SKY_ENVMAP = 0, 1
 SAMPLER_HALTON, SAMPLER_STRATIFIED = 0, 1
 FLAG_COUNT_TRAVERSAL, FLAG_TIME_KERNELS = 1, 2
@@ -37,7 +37,8 @@ class Material(C.Structure):
 
 class Texture(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32),
-                ("color", f3), ("texels", C.POINTER(C.c_float))]
+                ("color", f3), ("texels", C.POINTER(C.c_float)), ("texels8", C.POINTER(C.c_uint8)),
+                ("lut", C.POINTER(C.c_float))]
 
 
 class PointLight(C.Structure):

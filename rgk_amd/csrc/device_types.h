@@ -58,8 +58,9 @@ struct TriShade {
 
 // A texture as a material sees it, 16 B so it rides inside the material record (no second,
 // dependent descriptor fetch).  kind RGK_TEXREF_NONE = EmptyTexture (id -1: black, Empty()).
-// SOLID: a,b,c = colour (float bits).  IMAGE: a = width | height << 16, b = index of texel (0,0)
-// in the float4 texel pool.
+// SOLID: a,b,c = colour (float bits).  RGB32F: a = width | height << 16, b = index of texel (0,0)
+// in the float4 texel pool.  RGB8: same, b indexes the RGBA8 pool (one dword per texel) and c the
+// texture's 256-entry byte -> float table in the LUT pool.
 #define RGK_TEXREF_NONE 0xffffffffu
 struct TexRef {
     uint32_t kind, a, b, c;
@@ -122,6 +123,8 @@ struct DevScene {
     const TriShade* tri_shade;
     const DevMaterial* materials;
     const float4* texels; // RGBA float, A unused: one 16-byte load per texel
+    const uint32_t* texels8; // RGBA8, A unused: one dword per texel, decoded through `luts`
+    const float* luts;
     const DevPointLight* pointlights;
     const DevArealLight* areal;
     const DevArealTri* areal_tris;

@@ -186,9 +186,14 @@ __device__ __forceinline__ bool decide_and_rescale(float& sample, float probabil
 
 // ------------------------------------------------------------------ textures (a14)
 __device__ __forceinline__ float glm_repeat(float x) { return x - floorf(x); }
-__device__ __forceinline__ f3 texel_at(const DevScene& sc, uint32_t first, int idx) {
-    const float4 t = sc.texels[first + (uint32_t)idx];
-    return mk3(t.x, t.y, t.z);
+__device__ __forceinline__ f3 texel_at(const DevScene& sc, const TexRef t, int idx) {
+    if (t.kind == RGK_TEX_RGB8) { // the bytes the 8-bit loaders keep + the table that makes them the reference's floats
+        const uint32_t w = sc.texels8[t.b + (uint32_t)idx];
+        const float* lut = sc.luts + t.c;
+        return mk3(lut[w & 0xffu], lut[(w >> 8) & 0xffu], lut[(w >> 16) & 0xffu]);
+    }
+    const float4 v = sc.texels[t.b + (uint32_t)idx];
+    return mk3(v.x, v.y, v.z);
 }
 // ReadableTexture::GetPixelInterpolated, reference src/texture.cpp:35-77 (FileTexture) and
 // src/texture.hpp:64-80 (Solid / Empty)
@@ -205,8 +210,8 @@ __device__ inline f3 tex_get(const DevScene& sc, const TexRef t, float2 uv) {
     int iy1 = (iy0 != ysize - 1) ? iy0 + 1 : iy0;
     if (ix0 == -1) ix0 = 0;
     if (iy0 == -1) iy0 = 0;
-    f3 c00 = texel_at(sc, t.b, iy0 * xsize + ix0), c01 = texel_at(sc, t.b, iy0 * xsize + ix1);
-    f3 c10 = texel_at(sc, t.b, iy1 * xsize + ix0), c11 = texel_at(sc, t.b, iy1 * xsize + ix1);
+    f3 c00 = texel_at(sc, t, iy0 * xsize + ix0), c01 = texel_at(sc, t, iy0 * xsize + ix1);
+    f3 c10 = texel_at(sc, t, iy1 * xsize + ix0), c11 = texel_at(sc, t, iy1 * xsize + ix1);
     fy = 1.0f - fy;
     fx = 1.0f - fx;
     f3 c0s = fx * c00 + (1.0f - fx) * c01;
@@ -216,7 +221,7 @@ __device__ inline f3 tex_get(const DevScene& sc, const TexRef t, float2 uv) {
 // GetSlopeRight / GetSlopeBottom, reference src/texture.cpp:79-102
 __device__ inline void tex_slopes(const DevScene& sc, const TexRef t, float2 uv, float& right, float& bottom) {
     right = 0.f; bottom = 0.f;
-    if (t.kind != RGK_TEX_RGB32F) return;
+    if (t.kind != RGK_TEX_RGB32F && t.kind != RGK_TEX_RGB8) return;
     const int xsize = (int)(t.a & 0xffffu), ysize = (int)(t.a >> 16);
     int x = (int)(glm_repeat(uv.x) * xsize - 0.5f);
     int y = (int)(glm_repeat(uv.y) * ysize - 0.5f);
@@ -224,9 +229,9 @@ __device__ inline void tex_slopes(const DevScene& sc, const TexRef t, float2 uv,
     int y2 = (y != ysize - 1) ? y + 1 : y;
     if (x == -1) x = 0;
     if (y == -1) y = 0;
-    f3 here = texel_at(sc, t.b, y * xsize + x);
-    f3 tr = texel_at(sc, t.b, y * xsize + x2);
-    f3 tb = texel_at(sc, t.b, y2 * xsize + x);
+    f3 here = texel_at(sc, t, y * xsize + x);
+    f3 tr = texel_at(sc, t, y * xsize + x2);
+    f3 tb = texel_at(sc, t, y2 * xsize + x);
     float a = (here.x + here.y + here.z) / 3;
     right = a - (tr.x + tr.y + tr.z) / 3;
     bottom = a - (tb.x + tb.y + tb.z) / 3;

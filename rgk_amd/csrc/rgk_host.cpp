@@ -295,6 +295,8 @@ struct rgk_scene {
     DevBuf<TriShade> tri_shade;
     DevBuf<DevMaterial> materials;
     DevBuf<float4> texels;
+    DevBuf<uint32_t> texels8;
+    DevBuf<float> luts;
     DevBuf<DevPointLight> pointlights;
     DevBuf<DevArealLight> areal;
     DevBuf<DevArealTri> areal_tris;
@@ -318,7 +320,7 @@ struct rgk_scene {
         (void)hipSetDevice(device);
         for (auto e : events) (void)hipEventDestroy(e);
         if (h_counters) (void)hipHostFree(h_counters);
-        nodes.release(); tris.release(); tri_shade.release(); materials.release();
+        nodes.release(); tris.release(); tri_shade.release(); materials.release(); texels8.release(); luts.release();
         texels.release(); pointlights.release(); areal.release(); areal_tris.release(); ltc_ggx.release();
         ltc_beckmann.release(); hdims.release(); hperm.release();
         for (int i = 0; i < 2; i++) { rayA[i].release(); rayB[i].release(); }
@@ -432,7 +434,8 @@ int validate_desc(const rgk_scene_desc* d) {
     for (uint32_t i = 0; i < d->n_textures; i++) {
         const rgk_texture& t = d->textures[i];
         if (t.kind == RGK_TEX_RGB32F && (!t.texels || t.width == 0 || t.height == 0)) return fail(RGK_ERR_INVALID, "texture %u: empty image", i);
-        if (t.kind > RGK_TEX_RGB32F) return fail(RGK_ERR_INVALID, "texture %u: unknown kind", i);
+        if (t.kind == RGK_TEX_RGB8 && (!t.texels8 || !t.lut || t.width == 0 || t.height == 0)) return fail(RGK_ERR_INVALID, "texture %u: empty 8-bit image", i);
+        if (t.kind > RGK_TEX_RGB8) return fail(RGK_ERR_INVALID, "texture %u: unknown kind", i);
     }
     for (uint32_t i = 0; i < d->n_areal_lights; i++)
         for (uint32_t j = d->areal_offsets[i]; j < d->areal_offsets[i + 1]; j++)
@@ -573,6 +576,8 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
     }
     // textures: image texels into one float4 pool; a TexRef per (material, slot)
     std::vector<float4> pool;
+    std::vector<uint32_t> pool8;
+    std::vector<float> luts;
     std::vector<TexRef> trefs(d->n_textures);
     for (uint32_t i = 0; i < d->n_textures; i++) {
         const rgk_texture& t = d->textures[i];
@@ -580,6 +585,21 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
         o.kind = t.kind; o.a = o.b = o.c = 0;
         if (t.kind == RGK_TEX_SOLID) {
             std::memcpy(&o.a, &t.color[0], 4); std::memcpy(&o.b, &t.color[1], 4); std::memcpy(&o.c, &t.color[2], 4);
+        } else if (t.kind == RGK_TEX_RGB8) {
+            if (t.width > 65535 || t.height > 65535) return fail(RGK_ERR_UNSUPPORTED, "texture %u larger than 65535 texels on a side", i);
+            const size_t n = (size_t)t.width * t.height;
+            if (pool8.size() + n >= (1ull << 32)) return fail(RGK_ERR_UNSUPPORTED, "texel pool exceeds 2^32 texels");
+            o.a = t.width | (t.height << 16);
+            o.b = (uint32_t)pool8.size();
+            o.c = 0;
+            for (size_t k = 0; k + 256 <= luts.size(); k += 256) // share identical tables
+                if (std::memcmp(&luts[k], t.lut, 256 * sizeof(float)) == 0) { o.c = (uint32_t)k; goto have_lut; }
+            o.c = (uint32_t)luts.size();
+            luts.insert(luts.end(), t.lut, t.lut + 256);
+        have_lut:
+            pool8.reserve(pool8.size() + n);
+            for (size_t k = 0; k < n; k++)
+                pool8.push_back((uint32_t)t.texels8[3 * k] | ((uint32_t)t.texels8[3 * k + 1] << 8) | ((uint32_t)t.texels8[3 * k + 2] << 16));
         } else {
             if (t.width > 65535 || t.height > 65535) return fail(RGK_ERR_UNSUPPORTED, "texture %u larger than 65535 texels on a side", i);
             const size_t n = (size_t)t.width * t.height;
@@ -656,7 +676,8 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
 
     // ---- upload
     if ((rc = s->nodes.upload(qb.out)) || (rc = s->tris.upload(leaf_recs)) || (rc = s->tri_shade.upload(tsh)) ||
-        (rc = s->materials.upload(mats)) || (rc = s->texels.upload(pool)) || (rc = s->pointlights.upload(pls)) || (rc = s->areal.upload(als)) ||
+        (rc = s->materials.upload(mats)) || (rc = s->texels.upload(pool)) || (rc = s->texels8.upload(pool8)) ||
+        (rc = s->luts.upload(luts)) || (rc = s->pointlights.upload(pls)) || (rc = s->areal.upload(als)) ||
         (rc = s->areal_tris.upload(ats)) || (rc = s->hdims.upload(hd)) || (rc = s->hperm.upload(hp)))
         return rc;
     auto ltc_pack = [](const float* src) { // {m0,m2,m4,m6}{amp,0,0,0} per entry: two 16-byte loads
@@ -670,7 +691,7 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
     if (d->ltc_ggx && (rc = s->ltc_ggx.upload(ltc_pack(d->ltc_ggx)))) return rc;
     if (d->ltc_beckmann && (rc = s->ltc_beckmann.upload(ltc_pack(d->ltc_beckmann)))) return rc;
     ds.nodes = s->nodes.p; ds.tris = s->tris.p; ds.tri_shade = s->tri_shade.p;
-    ds.materials = s->materials.p; ds.texels = s->texels.p;
+    ds.materials = s->materials.p; ds.texels = s->texels.p; ds.texels8 = s->texels8.p; ds.luts = s->luts.p;
     ds.pointlights = s->pointlights.p; ds.areal = s->areal.p; ds.areal_tris = s->areal_tris.p;
     ds.ltc_ggx = s->ltc_ggx.p; ds.ltc_beckmann = s->ltc_beckmann.p; ds.hdims = s->hdims.p; ds.hperm = s->hperm.p;
     ds.n_pointlights = (uint32_t)pls.size(); ds.n_areal = (uint32_t)als.size();
@@ -741,11 +762,16 @@ static void make_camera(const rgk_camera* c, DevCamera& o) {
     o.lens_size = c->lens_size; o.xsize = c->xsize; o.ysize = c->ysize;
 }
 
-static size_t batch_paths() {
-    const char* e = getenv("RGK_BATCH_PATHS");
-    size_t b = e ? strtoull(e, nullptr, 10) : (size_t)1 << 25;
-    if (b < 1024) b = 1024;
-    return b;
+// Paths resident per pass.  The path state is sized for the machine, not for a cache: by default
+// 48 GB of the 288 GB HBM3E (measured on Sponza 1080p x 256 spp: 2^25 paths/pass 2235 Mpaths/s,
+// 2^27 2398, 2^28 2440 -- fewer, longer launches and shorter tails).  RGK_BATCH_PATHS overrides.
+static size_t batch_paths(uint32_t reverse) {
+    if (const char* e = getenv("RGK_BATCH_PATHS")) return std::max<size_t>(1024, strtoull(e, nullptr, 10));
+    const size_t per_path = 176 + (reverse ? 48 + 64 * (size_t)reverse + 16 * ((size_t)reverse + 1) + 48 * (size_t)reverse : 0);
+    const char* g = getenv("RGK_WORKSPACE_GB");
+    const double gb = g ? atof(g) : 48.0;
+    size_t b = (size_t)(gb * 1e9 / (double)per_path);
+    return std::min<size_t>(std::max<size_t>(b, 1024), (size_t)1 << 30);
 }
 
 int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_params* prm, const rgk_tile* tiles, uint32_t n_tiles,
@@ -763,23 +789,31 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
     for (uint32_t i = 0; i < n_tiles; i++) {
         const rgk_tile& t = tiles[i];
         if (t.x1 > prm->xres || t.y1 > prm->yres || t.x0 > t.x1 || t.y0 > t.y1) return fail(RGK_ERR_INVALID, "tile %u outside the frame", i);
-        uint32_t seed = t.seed;
-        for (uint32_t y = t.y0; y < t.y1; y++)
-            for (uint32_t x = t.x0; x < t.x1; x++) {
-                seed += 0x42424242u; // path_tracer.cpp:47
-                pxy.push_back(x | (y << 16));
-                pseed.push_back(seed);
-            }
+        // The seed of a pixel is fixed by its row-major rank k inside the task (RenderPixel is called in
+        // that order, tracer.cpp:8-9, and bumps the seed first, path_tracer.cpp:47).  The ORDER in which
+        // pixels occupy path slots is free: 8x8 blocks, so the 64 lanes of a wave start as a compact
+        // bundle of camera rays instead of two 32-pixel row segments (coherent traversal and shading).
+        const uint32_t tw = t.x1 - t.x0, th = t.y1 - t.y0;
+        for (uint32_t by = 0; by < th; by += 8)
+            for (uint32_t bx = 0; bx < tw; bx += 8)
+                for (uint32_t y = by; y < std::min(by + 8, th); y++)
+                    for (uint32_t x = bx; x < std::min(bx + 8, tw); x++) {
+                        const uint32_t k = y * tw + x;
+                        pxy.push_back((t.x0 + x) | ((t.y0 + y) << 16));
+                        pseed.push_back(t.seed + (k + 1u) * 0x42424242u);
+                    }
     }
     const size_t P = pxy.size();
     if (P == 0) return RGK_OK;
     int rc;
     if ((rc = s->pix_xy.upload(pxy)) || (rc = s->pix_seed.upload(pseed))) return rc;
-    const size_t B = batch_paths();
-    const size_t npix_pass = std::min(P, B);
-    const uint32_t ns_pass = (uint32_t)std::max<size_t>(1, std::min<size_t>(prm->multisample, B / npix_pass));
     // no light at all: TracePath builds no light sub-path (`reverse > 0 && valid light`), same as reverse == 0
     const uint32_t R = (s->dev.total_point_power + s->dev.total_areal_power > 0.0f) ? prm->reverse : 0u;
+    const size_t B = batch_paths(R);
+    const size_t npix_pass = std::min(P, B);
+    const uint32_t ns_max = (uint32_t)std::max<size_t>(1, std::min<size_t>(prm->multisample, B / npix_pass));
+    const uint32_t n_sample_passes = (prm->multisample + ns_max - 1) / ns_max;
+    const uint32_t ns_pass = (prm->multisample + n_sample_passes - 1) / n_sample_passes; // equal-sized passes
     if ((rc = ensure_workspace(s, npix_pass * ns_pass, R))) return rc;
     if ((rc = s->pixsum.alloc(P))) return rc;
 

@@ -253,7 +253,7 @@ def proxy_texture(sb, name):
     if key not in sb.tex_by_path:
         w, h = SPONZA_TEX_DIMS[name]
         img = procedural_texture(name, w, h)[::-1]  # JPEGs are stored flipped (Q12)
-        sb.add_image_texture(key, gamma_decode_u8(np.ascontiguousarray(img)))
+        sb.add_image_texture8(key, np.ascontiguousarray(img))
     return sb.tex_by_path[key]
 
 

@@ -140,7 +140,8 @@ class EXRTexture:
 class RenderDriver:
     """RenderDriver::RenderFrame / RenderRound for one process per GPU."""
 
-    def __init__(self, scene, cfg, camera, rank=0, world_size=1, device=None, sampler=capi.SAMPLER_HALTON, flags=0):
+    def __init__(self, scene, cfg, camera, rank=0, world_size=1, device=None, sampler=capi.SAMPLER_HALTON, flags=0,
+                 host_reduce=False):
         import torch
         self.scene, self.cfg, self.camera = scene, cfg, camera
         self.rank, self.world_size = rank, world_size
@@ -152,6 +153,7 @@ class RenderDriver:
         self.total_ob = EXRTexture(cfg.xres, cfg.yres, self.device)
         self.rounds_done = 0
         self.counters = []
+        self.host_reduce = host_reduce  # gloo rehearsal: reduce through host copies instead of RCCL
 
     def render_round(self, reduce=True):
         """One RenderRound: every rank renders its tiles into its private accumulator, then one
@@ -168,11 +170,19 @@ class RenderDriver:
         cnt = self.scene.render_round_device(self.camera, self.params, mine, ob.data.data_ptr(), ob.count.data_ptr())
         if self.world_size > 1 and reduce:
             import torch.distributed as dist
-            dist.reduce(ob.data, dst=0, op=dist.ReduceOp.SUM)
-            dist.reduce(ob.count, dst=0, op=dist.ReduceOp.SUM)
-            if self.rank == 0:
-                self.total_ob.data += ob.data
-                self.total_ob.count += ob.count
+            if self.host_reduce:
+                hd, hc = ob.data.cpu(), ob.count.cpu()
+                dist.reduce(hd, dst=0, op=dist.ReduceOp.SUM)
+                dist.reduce(hc, dst=0, op=dist.ReduceOp.SUM)
+                if self.rank == 0:
+                    self.total_ob.data += hd.to(self.total_ob.data.device)
+                    self.total_ob.count += hc.to(self.total_ob.count.device)
+            else:
+                dist.reduce(ob.data, dst=0, op=dist.ReduceOp.SUM)
+                dist.reduce(ob.count, dst=0, op=dist.ReduceOp.SUM)
+                if self.rank == 0:
+                    self.total_ob.data += ob.data
+                    self.total_ob.count += ob.count
         self.rounds_done += 1
         self.counters.append(cnt)
         return cnt

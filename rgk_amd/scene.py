@@ -128,10 +128,14 @@ def primitive_data(kind):
 
 
 # ----------------------------------------------------------------------- textures
+def gamma_lut():
+    """byte -> Color(byte/255).gammaDecode(2.2) (src/texture.cpp:203,252-254), the 256 floats the
+    reference's 8-bit loaders can produce."""
+    return np.power((np.arange(256, dtype=f32) / f32(255.0)).astype(f32), f32(2.2)).astype(f32)
+
+
 def gamma_decode_u8(img_u8):
-    """Color::gammaDecode(2.2) of byte/255 (src/texture.cpp:203,252-254): 256-entry exact LUT."""
-    lut = np.power((np.arange(256, dtype=f32) / f32(255.0)).astype(f32), f32(2.2)).astype(f32)
-    return lut[img_u8]
+    return gamma_lut()[img_u8]
 
 
 def load_texture_file(path):
@@ -148,7 +152,7 @@ def load_texture_file(path):
         pass
     else:
         raise ValueError(f"Texture format '{ext}' is not supported!")
-    return np.ascontiguousarray(gamma_decode_u8(a))
+    return np.ascontiguousarray(a)  # uint8; decoded through gamma_lut() (RGK_TEX_RGB8)
 
 
 class SceneBuilder:
@@ -182,6 +186,16 @@ class SceneBuilder:
         self.tex_by_path[key] = len(self.textures) - 1
         return self.tex_by_path[key]
 
+    def add_image_texture8(self, key, data_u8, lut=None):
+        """8-bit image (h, w, 3) uint8 as the reference's PNG/JPEG loaders store it + its byte->float table."""
+        if key in self.tex_by_path:
+            return self.tex_by_path[key]
+        data_u8 = np.ascontiguousarray(data_u8, dtype=np.uint8)
+        lut = gamma_lut() if lut is None else np.ascontiguousarray(lut, dtype=f32)
+        self.textures.append(dict(kind=capi.TEX_RGB8, color=(0.0, 0.0, 0.0), data=data_u8, lut=lut))
+        self.tex_by_path[key] = len(self.textures) - 1
+        return self.tex_by_path[key]
+
     def get_texture(self, path):
         """Scene::GetTexture (src/scene.cpp:250-278): cached by path; failure -> no texture."""
         if path == "":
@@ -190,7 +204,7 @@ class SceneBuilder:
         if key in self.tex_by_path:
             return self.tex_by_path[key]
         try:
-            return self.add_image_texture(key, load_texture_file(path))
+            return self.add_image_texture8(key, load_texture_file(path))
         except Exception as e:  # "Failed to load texture ..., ignoring it."
             if self.texture_fallback is not None:  # labelled proxy assets (rgk_amd.proxy)
                 t = self.texture_fallback(self, path)
@@ -414,8 +428,10 @@ class SceneBuilder:
         arrays = dict(V=self.V, N=self.N, T=self.T, UV=self.UV, F=self.F, FM=self.FM,
                       meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8))
         for i, t in enumerate(self.textures):
-            if t["kind"] == capi.TEX_RGB32F:
+            if t["kind"] in (capi.TEX_RGB32F, capi.TEX_RGB8):
                 arrays[f"tex{i}"] = t["data"]
+                if t["kind"] == capi.TEX_RGB8:
+                    arrays[f"lut{i}"] = t["lut"]
         np.savez_compressed(path, **arrays)
 
     @classmethod
@@ -434,7 +450,8 @@ class SceneBuilder:
         sb.pointlights, sb.areal, sb.sky = meta["pointlights"], meta["areal"], meta["sky"]
         sb.geometry_label = meta.get("geometry_label", "real")
         sb.textures = [dict(kind=t["kind"], color=tuple(t["color"]),
-                            data=(np.ascontiguousarray(z[f"tex{i}"]) if t["kind"] == capi.TEX_RGB32F else None))
+                            data=(np.ascontiguousarray(z[f"tex{i}"]) if t["kind"] != capi.TEX_SOLID else None),
+                            lut=(np.ascontiguousarray(z[f"lut{i}"]) if t["kind"] == capi.TEX_RGB8 else None))
                        for i, t in enumerate(meta["textures"])]
         sb.extra = meta.get("extra", {})
         return sb.finalize()
@@ -470,6 +487,10 @@ class SceneBuilder:
             if t["kind"] == capi.TEX_RGB32F:
                 tt.height, tt.width = t["data"].shape[0], t["data"].shape[1]
                 tt.texels = fp(t["data"])
+            elif t["kind"] == capi.TEX_RGB8:
+                tt.height, tt.width = t["data"].shape[0], t["data"].shape[1]
+                tt.texels8 = t["data"].ctypes.data_as(C.POINTER(C.c_uint8))
+                tt.lut = fp(t["lut"])
         d.n_textures, d.textures = len(self.textures), texs
         pls = (capi.PointLight * max(1, len(self.pointlights)))()
         for i, l in enumerate(self.pointlights):

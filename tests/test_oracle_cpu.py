@@ -264,6 +264,26 @@ def test_texture_sampling_kats(oracle):
     assert r_edge == 0.0
 
 
+def test_8bit_textures_equal_float_textures(oracle):
+    """RGK_TEX_RGB8 (bytes + byte->float table) must give exactly the texels of RGK_TEX_RGB32F."""
+    from rgk_amd.scene import gamma_lut
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    images = []
+    for as_float in (True, False):
+        sb = SceneBuilder()
+        t = sb.add_image_texture("f", gamma_lut()[img]) if as_float else sb.add_image_texture8("b", img)
+        m = sb.new_material("m", capi.BXDF_DIFFUSE); m["tex_diffuse"] = t; m["tex_bump"] = t; sb.register_material(m)
+        T = np.eye(4, dtype=np.float32); T[0, 0] = T[2, 2] = 2.0
+        sb.add_primitive("plane", T, "m", texscale=(3.0, 2.0, 1.0))
+        sb.add_point_light((0.5, 2.0, 0.3), (1, 1, 1), 10.0, 0.0)
+        sc = oracle.OracleScene(sb.to_desc())
+        cam = make_camera((0, 3, 0.01), (0, 0, 0), (0, 1, 0), fov=50, xres=48, yres=48)
+        acc, cnt, _ = sc.render_round(cam, make_params(48, 48, 4, 2, bumpscale=5.0), oracle.generate_task_list(48, 48))
+        images.append(acc)
+    assert images[0].max() > 0 and np.array_equal(images[0], images[1])
+
+
 def test_ltc_pdf_normalisation_and_sampling(oracle):
     """The LTC pdf integrates to ~amplitude * |sin(theta)|^-2-ish scale quirk aside: at normal-ish incidence and
     rough alpha it is a smooth lobe; sampled directions stay in the upper hemisphere and are unit length."""
