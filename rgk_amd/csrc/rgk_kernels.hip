@@ -356,9 +356,10 @@ void rgk_launch_raygen(hipStream_t st, const DevScene& sc, const DevCamera& cam,
 void rgk_launch_trace_closest(hipStream_t st, const DevScene& sc, int stack, bool count_stats, const float4* rayA, const float4* rayB,
                               const float2* nearfar, float4* hit, const uint32_t* count_ptr, uint32_t* fetch, unsigned long long* stats) {
     int grid = trace_grid(stack);
-#define L(C, S) k_trace_closest<C, S><<<grid, RGK_TRACE_BLOCK, 0, st>>>(sc, rayA, rayB, nearfar, hit, count_ptr, fetch, stats)
-    if (stack <= 32) { if (count_stats) L(true, 32); else L(false, 32); }
-    else { if (count_stats) L(true, 64); else L(false, 64); }
+#define L(C, S) { if (sc.node_wide) k_trace_closest<C, S, true><<<grid, RGK_TRACE_BLOCK, 0, st>>>(sc, rayA, rayB, nearfar, hit, count_ptr, fetch, stats); \
+                  else k_trace_closest<C, S, false><<<grid, RGK_TRACE_BLOCK, 0, st>>>(sc, rayA, rayB, nearfar, hit, count_ptr, fetch, stats); }
+    if (stack <= 32) { if (count_stats) L(true, 32) else L(false, 32) }
+    else { if (count_stats) L(true, 64) else L(false, 64) }
 #undef L
 }
 
@@ -366,9 +367,10 @@ void rgk_launch_trace_shadow(hipStream_t st, const DevScene& sc, int stack, bool
                              const float4* shC, float4* tot, uint8_t* vis_out, int mode, float* splat_rgb, const uint32_t* count_ptr,
                              uint32_t* fetch, unsigned long long* stats) {
     int grid = trace_grid(stack);
-#define L(C, S) k_trace_shadow<C, S><<<grid, RGK_TRACE_BLOCK, 0, st>>>(sc, shA, shB, shC, tot, vis_out, mode, splat_rgb, count_ptr, fetch, stats)
-    if (stack <= 32) { if (count_stats) L(true, 32); else L(false, 32); }
-    else { if (count_stats) L(true, 64); else L(false, 64); }
+#define L(C, S) { if (sc.node_wide) k_trace_shadow<C, S, true><<<grid, RGK_TRACE_BLOCK, 0, st>>>(sc, shA, shB, shC, tot, vis_out, mode, splat_rgb, count_ptr, fetch, stats); \
+                  else k_trace_shadow<C, S, false><<<grid, RGK_TRACE_BLOCK, 0, st>>>(sc, shA, shB, shC, tot, vis_out, mode, splat_rgb, count_ptr, fetch, stats); }
+    if (stack <= 32) { if (count_stats) L(true, 32) else L(false, 32) }
+    else { if (count_stats) L(true, 64) else L(false, 64) }
 #undef L
 }
 
