@@ -20,15 +20,16 @@ def up_to_date():
     return all(os.path.getmtime(os.path.join(CSRC, f)) <= t for f in SOURCES + HEADERS)
 
 
-def build(force=False, verbose=True):
-    if up_to_date() and not force:
+def build(force=False, verbose=True, extra=(), out=None):
+    """`extra` / `out`: tuning variants (-DRGK_TOP_NODES=...), built beside the product library."""
+    if out is None and up_to_date() and not force:
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    cmd = [hipcc] + FLAGS + list(extra) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out or LIB]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    return LIB
+    return out or LIB
 
 
 if __name__ == "__main__":

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "librgk_hip.so")
+LIB_PATH = os.environ.get("RGK_LIB") or os.path.join(HERE, "csrc", "librgk_hip.so")  # RGK_LIB: a tuning variant
 
 # rgk_bxdf_kind
 BXDF_DIFFUSE, BXDF_MIRROR, BXDF_DIELECTRIC, BXDF_TRANSPARENT, BXDF_MIX = 0, 1, 2, 3, 4

@@ -36,17 +36,6 @@ struct QNode {
     float sy, sz;
 };
 
-// Alternative node format (DevScene::node_wide): the same 4-wide node with full-precision planes,
-// two lines (128 B).  Planes are stored RELATIVE to the scene-box centre and rounded outward, in
-// rows {lo.x[4]} {hi.x[4]} {lo.y[4]} {hi.y[4]} {lo.z[4]} {hi.z[4]} so a lane picks its near / far
-// row by address (row ^ 16 bytes by the sign of 1/d) and needs no decode and no select:
-// t = plane * (1/d) + (-(o - centre)/d), one packed fma per two planes.  Unused slot: lo = +inf, hi = -inf.
-struct WNode {
-    float plane[6][4];
-    int32_t child[4];
-    int32_t pad[4];
-};
-
 // Everything Triangle::TestIntersection (reference src/primitives.cpp:75-166) reads for
 // one triangle, with the vertex differences it recomputes per call hoisted to commit time
 // (same float subtractions on the same operands, so the values are bit-identical).
@@ -129,7 +118,7 @@ struct DevCamera {
 };
 
 struct DevScene {
-    const void* nodes; // QNode[] or WNode[] (node_wide)
+    const QNode* nodes;
     const TriIsect* tris;
     const TriShade* tri_shade;
     const DevMaterial* materials;
@@ -148,9 +137,7 @@ struct DevScene {
     float epsilon;
     float bb_min[3], bb_max[3];
     uint32_t has_texcoords;
-    uint32_t node_wide;
     uint32_t walk_q; // traversal scheduling knob (rgk_trace.h), 0 = walk until every lane is at a leaf
-    float centre[3]; // scene-box centre the WNode planes are relative to
     uint32_t sky_mode;
     float sky_color[3];
     float sky_intensity, sky_rotate;

@@ -182,9 +182,6 @@ struct BvhBuilder {
 struct QbvhBuilder {
     const std::vector<BvhNode>& bn;
     std::vector<QNode> out;
-    std::vector<WNode> wout; // the same tree with full-precision planes (filled when `wide`)
-    bool wide = false;
-    float centre[3] = {0.f, 0.f, 0.f};
     uint32_t max_stack = 0, max_depth = 0;
     explicit QbvhBuilder(const std::vector<BvhNode>& b) : bn(b) {}
     struct Child { int ref; Box box; };
@@ -248,29 +245,10 @@ struct QbvhBuilder {
         }
         for (size_t i = 0; i < 4; i++) q.child[i] = RGK_QNODE_EMPTY;
         out[idx] = q;
-        if (wide) {
-            WNode w;
-            std::memset(&w, 0, sizeof(w));
-            for (int a = 0; a < 3; a++)
-                for (size_t i = 0; i < 4; i++) {
-                    float lo = std::numeric_limits<float>::infinity(), hi = -std::numeric_limits<float>::infinity();
-                    if (i < ch.size()) { // relative to the scene centre, rounded outward
-                        lo = ch[i].box.mn[a] - centre[a];
-                        if ((double)lo > (double)ch[i].box.mn[a] - (double)centre[a]) lo = std::nextafterf(lo, -std::numeric_limits<float>::infinity());
-                        hi = ch[i].box.mx[a] - centre[a];
-                        if ((double)hi < (double)ch[i].box.mx[a] - (double)centre[a]) hi = std::nextafterf(hi, std::numeric_limits<float>::infinity());
-                    }
-                    w.plane[2 * a][i] = lo; w.plane[2 * a + 1][i] = hi;
-                }
-            for (size_t i = 0; i < 4; i++) w.child[i] = RGK_QNODE_EMPTY;
-            if (wout.size() <= (size_t)idx) wout.resize(idx + 1);
-            wout[idx] = w;
-        }
         for (size_t i = 0; i < ch.size(); i++) {
             int ref = ch[i].ref;
             if (ref >= 0) ref = collapse(ref, depth + 1, stack_before + pushed);
             out[idx].child[i] = ref;
-            if (wide) wout[idx].child[i] = ref;
         }
         return idx;
     }
@@ -313,7 +291,6 @@ struct rgk_scene {
     int stack = 32;
     // scene data
     DevBuf<QNode> nodes;
-    DevBuf<WNode> wnodes;
     DevBuf<TriIsect> tris;
     DevBuf<TriShade> tri_shade;
     DevBuf<DevMaterial> materials;
@@ -343,7 +320,7 @@ struct rgk_scene {
         (void)hipSetDevice(device);
         for (auto e : events) (void)hipEventDestroy(e);
         if (h_counters) (void)hipHostFree(h_counters);
-        nodes.release(); wnodes.release(); tris.release(); tri_shade.release(); materials.release(); texels8.release(); luts.release();
+        nodes.release(); tris.release(); tri_shade.release(); materials.release(); texels8.release(); luts.release();
         texels.release(); pointlights.release(); areal.release(); areal_tris.release(); ltc_ggx.release();
         ltc_beckmann.release(); hdims.release(); hperm.release();
         for (int i = 0; i < 2; i++) { rayA[i].release(); rayB[i].release(); }
@@ -494,7 +471,7 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
     struct Guard { rgk_scene* s; ~Guard() { delete s; } } guard{s};
     HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
 
-    const uint32_t nt = d->n_triangles, nv = d->n_vertices;
+    const uint32_t nt = d->n_triangles;
     auto vert = [&](uint32_t i) { return V3{d->vertices[3 * i], d->vertices[3 * i + 1], d->vertices[3 * i + 2]}; };
 
     // ---- Commit: bounds, epsilon (scene.cpp:364-395)
@@ -577,11 +554,6 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
     }
     QbvhBuilder qb(nodes);
     qb.out.reserve(nodes.size() / 2 + 1);
-    { // node format: RGK_NODES=q8 (64-byte quantised, default) | wide (128-byte float planes)
-        const char* e = std::getenv("RGK_NODES");
-        qb.wide = (e && std::strcmp(e, "wide") == 0);
-        for (int a = 0; a < 3; a++) qb.centre[a] = 0.5f * (ds.bb_min[a] + ds.bb_max[a]);
-    }
     if (qb.collapse(0, 0, 0) != 0) return fail(RGK_ERR_DEVICE, "internal: QBVH root is not node 0");
     if (qb.max_stack + 1 > 64) return fail(RGK_ERR_UNSUPPORTED, "BVH needs %u traversal-stack entries (max 64)", qb.max_stack + 1);
     s->stack = (qb.max_stack + 1 <= 32) ? 32 : 64;
@@ -703,9 +675,7 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
     build_halton(hd, hp);
 
     // ---- upload
-    if (qb.wide) { if ((rc = s->wnodes.upload(qb.wout))) return rc; }
-    else if ((rc = s->nodes.upload(qb.out))) return rc;
-    if ((rc = s->tris.upload(leaf_recs)) || (rc = s->tri_shade.upload(tsh)) ||
+    if ((rc = s->nodes.upload(qb.out)) || (rc = s->tris.upload(leaf_recs)) || (rc = s->tri_shade.upload(tsh)) ||
         (rc = s->materials.upload(mats)) || (rc = s->texels.upload(pool)) || (rc = s->texels8.upload(pool8)) ||
         (rc = s->luts.upload(luts)) || (rc = s->pointlights.upload(pls)) || (rc = s->areal.upload(als)) ||
         (rc = s->areal_tris.upload(ats)) || (rc = s->hdims.upload(hd)) || (rc = s->hperm.upload(hp)))
@@ -720,11 +690,9 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
     };
     if (d->ltc_ggx && (rc = s->ltc_ggx.upload(ltc_pack(d->ltc_ggx)))) return rc;
     if (d->ltc_beckmann && (rc = s->ltc_beckmann.upload(ltc_pack(d->ltc_beckmann)))) return rc;
-    ds.nodes = qb.wide ? (const void*)s->wnodes.p : (const void*)s->nodes.p;
-    ds.node_wide = qb.wide ? 1u : 0u;
+    ds.nodes = s->nodes.p;
     { const char* e = std::getenv("RGK_WALK_Q"); ds.walk_q = e ? (uint32_t)std::atoi(e) : 4u; }
-    if (std::getenv("RGK_DEBUG_BVH")) std::fprintf(stderr, "[rgk] bvh4 nodes %zu max_stack %u max_depth %u wide %d\n", qb.out.size(), qb.max_stack, qb.max_depth, (int)qb.wide);
-    for (int a = 0; a < 3; a++) ds.centre[a] = qb.centre[a];
+    if (std::getenv("RGK_DEBUG_BVH")) std::fprintf(stderr, "[rgk] bvh4 nodes %zu max_stack %u max_depth %u\n", qb.out.size(), qb.max_stack, qb.max_depth);
     ds.tris = s->tris.p; ds.tri_shade = s->tri_shade.p;
     ds.materials = s->materials.p; ds.texels = s->texels.p; ds.texels8 = s->texels8.p; ds.luts = s->luts.p;
     ds.pointlights = s->pointlights.p; ds.areal = s->areal.p; ds.areal_tris = s->areal_tris.p;
@@ -740,7 +708,7 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
     inf.epsilon = eps;
     for (int a = 0; a < 3; a++) { inf.bbox_min[a] = ds.bb_min[a]; inf.bbox_max[a] = ds.bb_max[a]; }
     inf.total_areal_power = total_areal; inf.total_point_power = total_point;
-    inf.n_nodes = (uint32_t)qb.out.size(); inf.node_bytes = qb.wide ? (uint32_t)sizeof(WNode) : RGK_NODE_BYTES; inf.tri_bytes = RGK_TRI_BYTES;
+    inf.n_nodes = (uint32_t)qb.out.size(); inf.node_bytes = RGK_NODE_BYTES; inf.tri_bytes = RGK_TRI_BYTES;
     inf.max_depth = max_depth; inf.n_leaf_refs = (uint32_t)leaf_recs.size();
     guard.s = nullptr;
     *out = s;

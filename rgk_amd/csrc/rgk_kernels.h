@@ -3,8 +3,15 @@
 #include <hip/hip_runtime.h>
 #include "device_types.h"
 
+#ifndef RGK_TRACE_BLOCK
 #define RGK_TRACE_BLOCK 256
+#endif
+#ifndef RGK_SHADE_WAVES
+#define RGK_SHADE_WAVES 4 // waves per SIMD the shade kernel is compiled for (128 VGPRs)
+#endif
+#ifndef RGK_SHADE_BLOCK
 #define RGK_SHADE_BLOCK 512
+#endif
 #define RGK_MAX_DEPTH 62
 
 // device counter block (uint32), zeroed per pass by k_init_counters

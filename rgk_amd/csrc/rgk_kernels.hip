@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void k_raygen(const DevScene sc, const DevCame
 
 // ------------------------------------------------------------------ K3+K4+K6+K7: shade
 
-__global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade(const DevScene sc, const DevCamera cam, const PassParams pp, const uint32_t bounce,
+__global__ __launch_bounds__(RGK_SHADE_BLOCK, RGK_SHADE_WAVES) void k_shade(const DevScene sc, const DevCamera cam, const PassParams pp, const uint32_t bounce,
                                                             const float4* __restrict__ rayA, const float4* __restrict__ rayB,
                                                             const float4* __restrict__ hit, float4* __restrict__ thr, float4* __restrict__ tot,
                                                             float4* __restrict__ nextA, float4* __restrict__ nextB, float4* __restrict__ shA,
@@ -332,6 +332,7 @@ __global__ void k_sampler_eval(const DevScene sc, uint32_t n, const uint32_t* se
 }
 
 // ------------------------------------------------------------------ launch wrappers (host)
+#define RGK_STACK_BIG (RGK_TRACE_BLOCK <= 256 ? 64 : 32) // tuning variants with larger workgroups only serve 32-entry stacks
 static inline int trace_grid(int stack) {
     // LDS-limited residency: STACK*256*4 B per block out of 160 KiB, 256 CUs
     int per_cu = (160 * 1024) / (stack * RGK_TRACE_BLOCK * 4);
@@ -356,10 +357,9 @@ void rgk_launch_raygen(hipStream_t st, const DevScene& sc, const DevCamera& cam,
 void rgk_launch_trace_closest(hipStream_t st, const DevScene& sc, int stack, bool count_stats, const float4* rayA, const float4* rayB,
                               const float2* nearfar, float4* hit, const uint32_t* count_ptr, uint32_t* fetch, unsigned long long* stats) {
     int grid = trace_grid(stack);
-#define L(C, S) { if (sc.node_wide) k_trace_closest<C, S, true><<<grid, RGK_TRACE_BLOCK, 0, st>>>(sc, rayA, rayB, nearfar, hit, count_ptr, fetch, stats); \
-                  else k_trace_closest<C, S, false><<<grid, RGK_TRACE_BLOCK, 0, st>>>(sc, rayA, rayB, nearfar, hit, count_ptr, fetch, stats); }
+#define L(C, S) { k_trace_closest<C, S><<<grid, RGK_TRACE_BLOCK, 0, st>>>(sc, rayA, rayB, nearfar, hit, count_ptr, fetch, stats); }
     if (stack <= 32) { if (count_stats) L(true, 32) else L(false, 32) }
-    else { if (count_stats) L(true, 64) else L(false, 64) }
+    else { if (count_stats) L(true, RGK_STACK_BIG) else L(false, RGK_STACK_BIG) }
 #undef L
 }
 
@@ -367,17 +367,16 @@ void rgk_launch_trace_shadow(hipStream_t st, const DevScene& sc, int stack, bool
                              const float4* shC, float4* tot, uint8_t* vis_out, int mode, float* splat_rgb, const uint32_t* count_ptr,
                              uint32_t* fetch, unsigned long long* stats) {
     int grid = trace_grid(stack);
-#define L(C, S) { if (sc.node_wide) k_trace_shadow<C, S, true><<<grid, RGK_TRACE_BLOCK, 0, st>>>(sc, shA, shB, shC, tot, vis_out, mode, splat_rgb, count_ptr, fetch, stats); \
-                  else k_trace_shadow<C, S, false><<<grid, RGK_TRACE_BLOCK, 0, st>>>(sc, shA, shB, shC, tot, vis_out, mode, splat_rgb, count_ptr, fetch, stats); }
+#define L(C, S) { k_trace_shadow<C, S><<<grid, RGK_TRACE_BLOCK, 0, st>>>(sc, shA, shB, shC, tot, vis_out, mode, splat_rgb, count_ptr, fetch, stats); }
     if (stack <= 32) { if (count_stats) L(true, 32) else L(false, 32) }
-    else { if (count_stats) L(true, 64) else L(false, 64) }
+    else { if (count_stats) L(true, RGK_STACK_BIG) else L(false, RGK_STACK_BIG) }
 #undef L
 }
 
 void rgk_launch_shade(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t bounce, const float4* rayA,
                       const float4* rayB, const float4* hit, float4* thr, float4* tot, float4* nextA, float4* nextB, float4* shA,
                       float4* shB, float4* shC, uint32_t* counters) {
-    k_shade<<<256 * 4, RGK_SHADE_BLOCK, 0, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
+    k_shade<<<256 * 4 * (512 / RGK_SHADE_BLOCK), RGK_SHADE_BLOCK, 0, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
 }
 
 void rgk_launch_resolve(hipStream_t st, const PassParams& pp, const float4* tot, float4* pixsum, float* accum_rgb, uint32_t* accum_count) {
@@ -414,12 +413,12 @@ void rgk_launch_raygen_camera(hipStream_t st, const DevScene& sc, const DevCamer
 void rgk_launch_shade_light(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t k, const float4* rayA,
                             const float4* rayB, const float4* hit, float4* thr, float4* nextA, float4* nextB, float4* shA, float4* shB,
                             float4* shC, uint32_t* counters) {
-    k_shade_light<<<256 * 4, RGK_SHADE_BLOCK, 0, st>>>(sc, cam, pp, k, rayA, rayB, hit, thr, nextA, nextB, shA, shB, shC, counters);
+    k_shade_light<<<256 * 4 * (512 / RGK_SHADE_BLOCK), RGK_SHADE_BLOCK, 0, st>>>(sc, cam, pp, k, rayA, rayB, hit, thr, nextA, nextB, shA, shB, shC, counters);
 }
 void rgk_launch_shade_bdpt(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t bounce,
                            const float4* rayA, const float4* rayB, const float4* hit, float4* thr, float4* tot, float4* nextA, float4* nextB,
                            float4* shA, float4* shB, float4* shC, uint32_t* counters) {
-    k_shade_bdpt<<<256 * 4, RGK_SHADE_BLOCK, 0, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
+    k_shade_bdpt<<<256 * 4 * (512 / RGK_SHADE_BLOCK), RGK_SHADE_BLOCK, 0, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
 }
 void rgk_launch_finish_vertex(hipStream_t st, const PassParams& pp, uint32_t bounce, const float4* rayB, float4* tot, const uint32_t* counters) {
     k_finish_vertex<<<256 * 8, 256, 0, st>>>(pp, bounce, rayB, tot, counters);

@@ -13,6 +13,12 @@
 // chunk of the ray queue and, whenever a quarter of its lanes are idle, hands them fresh rays
 // (ballot + prefix popcount); a lane that drains its stack stores its hit and goes idle.
 // The per-lane traversal stack lives in LDS as [entry][lane] (bank = lane: conflict-free).
+//
+// Counters after the refill (profiles/r01_trace_pmc.txt): VALU issue ~100 % of SIMD cycles AND the vector L1
+// ~90 % occupied (TA busy 67 % + 32 % pending-line stalls; L1 hit rate 93 %) -- the kernel is co-limited, which is
+// why two one-sided trades lost: 128-byte nodes with full-precision planes (85 VALU per node instead of 150 thanks
+// to packed fma and no decode, but 7 loads per visit instead of 4: 30.1 vs 25.9 ms) and keeping the top 96..512
+// nodes in LDS (fewer L1 lookups, but a divergent LDS / global choice per visit: 23.7..24.1 vs 23.0 ms).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "rgk_device.h"
@@ -78,9 +84,7 @@ __device__ __forceinline__ float cvt_ubyte(uint32_t w, int c) { return (float)((
 // ANY = false: closest hit, results to hit[i] = {t, alpha, beta, tri}.
 // ANY = true : Scene::Visibility; vis_out[i] = visible, or (path mode) tot[slot] += radiance if visible.
 //   q0 = {o.xyz, d.x}; q1 = {d.y, d.z, ignore | far, slot}; q2 = {radiance.rgb, near} (shadow only)
-typedef float v2f __attribute__((ext_vector_type(2)));
-
-template <bool ANY, bool COUNT, int STACK, bool WIDE>
+template <bool ANY, bool COUNT, int STACK>
 __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float4* __restrict__ q0, const float4* __restrict__ q1,
                                                  const float4* __restrict__ q2, const float2* __restrict__ nearfar,
                                                  float4* __restrict__ hit, float4* __restrict__ tot, uint8_t* __restrict__ vis_out,
@@ -92,7 +96,6 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
     const float eps = sc.epsilon;
     const int walk_q = (int)sc.walk_q;
     const float4* __restrict__ nodes = reinterpret_cast<const float4*>(sc.nodes);
-    const char* __restrict__ nodes_b = reinterpret_cast<const char*>(sc.nodes);
     const float4* __restrict__ tris = reinterpret_cast<const float4*>(sc.tris);
     const uint32_t chunk = fetch_chunk(count, gridDim.x * (RGK_TRACE_BLOCK / 64));
     uint32_t w_next = 0, w_end = 0; // wave-uniform: this wave's slice of the queue
@@ -100,8 +103,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
     // per-lane ray state
     bool active = false;
     uint32_t idx = 0, ignore = 0xffffffffu, slot = 0;
-    f3 o = mk3(0.f, 0.f, 0.f), d = o, inv = o, rad = o, nb = o;
-    uint32_t onx = 0, ofx = 16, ony = 32, ofy = 48, onz = 64, ofz = 80; // WIDE: byte offsets of this ray's near / far plane rows
+    f3 o = mk3(0.f, 0.f, 0.f), d = o, inv = o, rad = o;
     float tlo = 0.f, thi = 0.f, best_t = 0.f, best_a = 0.f, best_b = 0.f;
     int best_tri = -1, cur = STACK_SENTINEL, sp = 0;
 
@@ -141,11 +143,6 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
                     if (clip_to_scene(sc, o, d, tn, tf, t0, t1)) {
                         tlo = t0 - eps; thi = t1 + eps;
                         inv = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
-                        if (WIDE) {
-                            nb = mk3(-((o.x - sc.centre[0]) * inv.x), -((o.y - sc.centre[1]) * inv.y), -((o.z - sc.centre[2]) * inv.z));
-                            const uint32_t gx = (__float_as_uint(inv.x) >> 31) << 4, gy = (__float_as_uint(inv.y) >> 31) << 4, gz = (__float_as_uint(inv.z) >> 31) << 4;
-                            onx = gx; ofx = gx ^ 16u; ony = 32u + gy; ofy = 32u + (gy ^ 16u); onz = 64u + gz; ofz = 64u + (gz ^ 16u);
-                        }
                         cur = 0;
                     } else cur = STACK_SENTINEL; // misses the scene box: reported below as a miss
                     active = true;
@@ -176,35 +173,6 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
             int ref[4];
             if (COUNT) n_nodes++;
             const float limit = ANY ? thi : fminf(thi, best_t);
-            if (WIDE) {
-                // one 128-byte WNode; near / far rows picked by address, t = plane * (1/d) + nb, two planes per packed fma.
-                // (Box tests only steer the walk: they never produce a result.  Planes are relative to the scene
-                // centre, so the fma form is off by at most diag * 2^-24 in space, far inside the eps pad of the boxes.)
-                const uint32_t base = (uint32_t)cur << 7;
-                const float4 nx = *reinterpret_cast<const float4*>(nodes_b + (base + onx)), fx = *reinterpret_cast<const float4*>(nodes_b + (base + ofx));
-                const float4 ny = *reinterpret_cast<const float4*>(nodes_b + (base + ony)), fy = *reinterpret_cast<const float4*>(nodes_b + (base + ofy));
-                const float4 nz = *reinterpret_cast<const float4*>(nodes_b + (base + onz)), fz = *reinterpret_cast<const float4*>(nodes_b + (base + ofz));
-                const float4 ch = *reinterpret_cast<const float4*>(nodes_b + (base + 96u));
-                ref[0] = __float_as_int(ch.x); ref[1] = __float_as_int(ch.y); ref[2] = __float_as_int(ch.z); ref[3] = __float_as_int(ch.w);
-                const v2f ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
-                const v2f bx = {nb.x, nb.x}, by = {nb.y, nb.y}, bz = {nb.z, nb.z};
-#define RGK_PK(v, lo, hi, i, b) const v2f v = __builtin_elementwise_fma((v2f){lo, hi}, i, b)
-                RGK_PK(a0x, nx.x, nx.y, ix, bx); RGK_PK(a1x, nx.z, nx.w, ix, bx); RGK_PK(b0x, fx.x, fx.y, ix, bx); RGK_PK(b1x, fx.z, fx.w, ix, bx);
-                RGK_PK(a0y, ny.x, ny.y, iy, by); RGK_PK(a1y, ny.z, ny.w, iy, by); RGK_PK(b0y, fy.x, fy.y, iy, by); RGK_PK(b1y, fy.z, fy.w, iy, by);
-                RGK_PK(a0z, nz.x, nz.y, iz, bz); RGK_PK(a1z, nz.z, nz.w, iz, bz); RGK_PK(b0z, fz.x, fz.y, iz, bz); RGK_PK(b1z, fz.z, fz.w, iz, bz);
-#undef RGK_PK
-                const float t0x[4] = {a0x.x, a0x.y, a1x.x, a1x.y}, t1x[4] = {b0x.x, b0x.y, b1x.x, b1x.y};
-                const float t0y[4] = {a0y.x, a0y.y, a1y.x, a1y.y}, t1y[4] = {b0y.x, b0y.y, b1y.x, b1y.y};
-                const float t0z[4] = {a0z.x, a0z.y, a1z.x, a1z.y}, t1z[4] = {b0z.x, b0z.y, b1z.x, b1z.y};
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const float tn = fmaxf(fmaxf(fmaxf(t0x[c], t0y[c]), t0z[c]), tlo);
-                    const float tf = fminf(fminf(fminf(t1x[c], t1y[c]), t1z[c]), limit);
-                    const bool h = tn <= tf;
-                    te[c] = h ? tn : __builtin_inff();
-                    if (!h) ref[c] = STACK_SENTINEL;
-                }
-            } else {
             // one 64-byte QNode: {p.xyz, sx} {child[4]} {qlo.x qlo.y qlo.z qhi.x} {qhi.y qhi.z sy sz}
             const float4 n0 = nodes[4 * cur + 0], n1 = nodes[4 * cur + 1], n2 = nodes[4 * cur + 2], n3 = nodes[4 * cur + 3];
             const float sx = n0.w, sy = n3.z, sz = n3.w; // per-axis quantisation step (a power of two)
@@ -235,7 +203,6 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
                 const bool h = tn <= tf;
                 te[c] = h ? tn : __builtin_inff();
                 if (!h) ref[c] = STACK_SENTINEL;
-            }
             }
             if (!ANY) {
                 // sort the four (entry distance, ref) pairs ascending: 5-comparator network
@@ -306,14 +273,14 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
 }
 
 // ------------------------------------------------------------------ K2: closest hit
-template <bool COUNT, int STACK, bool WIDE>
+template <bool COUNT, int STACK>
 __global__ __launch_bounds__(RGK_TRACE_BLOCK) void k_trace_closest(const DevScene sc, const float4* __restrict__ rayA,
                                                                     const float4* __restrict__ rayB, const float2* __restrict__ nearfar,
                                                                     float4* __restrict__ hit, const uint32_t* __restrict__ count_ptr,
                                                                     uint32_t* __restrict__ fetch, unsigned long long* __restrict__ stats) {
     __shared__ int lds_stack[STACK * RGK_TRACE_BLOCK];
     uint32_t n_nodes = 0, n_tris = 0;
-    trace_persistent<false, COUNT, STACK, WIDE>(sc, rayA, rayB, nullptr, nearfar, hit, nullptr, nullptr, 0, nullptr, *count_ptr, fetch,
+    trace_persistent<false, COUNT, STACK>(sc, rayA, rayB, nullptr, nearfar, hit, nullptr, nullptr, 0, nullptr, *count_ptr, fetch,
                                           lds_stack + threadIdx.x, n_nodes, n_tris);
     if (COUNT) {
         atomicAdd(&stats[0], (unsigned long long)n_nodes);
@@ -323,7 +290,7 @@ __global__ __launch_bounds__(RGK_TRACE_BLOCK) void k_trace_closest(const DevScen
 
 // ------------------------------------------------------------------ K5: shadow rays + accumulate
 // shA = (o.xyz, d.x)  shB = (d.y, d.z, far, slot)  shC = (radiance.rgb, near)
-template <bool COUNT, int STACK, bool WIDE>
+template <bool COUNT, int STACK>
 __global__ __launch_bounds__(RGK_TRACE_BLOCK) void k_trace_shadow(const DevScene sc, const float4* __restrict__ shA,
                                                                    const float4* __restrict__ shB, const float4* __restrict__ shC,
                                                                    float4* __restrict__ tot, uint8_t* __restrict__ vis_out,
@@ -332,7 +299,7 @@ __global__ __launch_bounds__(RGK_TRACE_BLOCK) void k_trace_shadow(const DevScene
                                                                    unsigned long long* __restrict__ stats) {
     __shared__ int lds_stack[STACK * RGK_TRACE_BLOCK];
     uint32_t n_nodes = 0, n_tris = 0;
-    trace_persistent<true, COUNT, STACK, WIDE>(sc, shA, shB, shC, nullptr, nullptr, tot, vis_out, mode, splat_rgb, *count_ptr, fetch,
+    trace_persistent<true, COUNT, STACK>(sc, shA, shB, shC, nullptr, nullptr, tot, vis_out, mode, splat_rgb, *count_ptr, fetch,
                                          lds_stack + threadIdx.x, n_nodes, n_tris);
     if (COUNT) {
         atomicAdd(&stats[2], (unsigned long long)n_nodes);

@@ -103,3 +103,25 @@ class Workload:
     def params(self, sampler=capi.SAMPLER_HALTON, flags=0):
         return make_params(self.xres, self.yres, self.multisample, self.depth, self.clamp, self.russian, self.bumpscale,
                            self.reverse, sampler, flags)
+
+
+class SceneFixture:
+    """A committed scene fixture (tests/golden/scene_<name>.npz, made by tools/make_fixtures.py from a scene
+    the reference ships complete) with the render parameters of its config file."""
+
+    def __init__(self, path, scale=1.0, spp=None, depth=None):
+        sb = SceneBuilder.load_npz(path)
+        ex = sb.extra
+        self.name = ex.get("source", os.path.basename(path))
+        self.builder = sb
+        self.xres, self.yres = max(1, int(ex["xres"] * scale)), max(1, int(ex["yres"] * scale))
+        self.multisample = spp or ex["multisample"]
+        c = ex["camera"]
+        self.camera = make_camera(c["pos"], c["lookat"], c["up"], fov=c.get("fov"), focal=c.get("focal"), xres=self.xres,
+                                  yres=self.yres, focus_plane=c.get("focus_plane", 1.0), lens_size=c.get("lens_size", 0.0))
+        self.depth = depth or ex["depth"]
+        self.clamp, self.russian, self.bumpscale, self.reverse = ex["clamp"], ex["russian"], ex["bumpscale"], ex["reverse"]
+        self.rounds = 1
+        self.geometry = "real"
+
+    params = Workload.params

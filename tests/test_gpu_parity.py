@@ -156,6 +156,42 @@ def test_triangle_soup_with_degenerates(rd, oracle):
     assert check_closest(g, o, make_rays(oo, dd), o.info().epsilon, max_unexplained=5e-5) > 0.999
 
 
+# ----------------------------------------------------------------------- scenes the reference ships complete
+REFERENCE_SCENES = {  # name -> (scale, spp, image rel-L2 bound): fixtures made by tools/make_fixtures.py
+    "rubiks-bump": (0.15, 16, 1e-3),          # PNG texture + bump map, point light, bumpscale 15
+    "cube3": (0.12, 16, 2e-3),                # 8966 faces, LTC Beckmann, sphere light size 0.4, russian 0.6
+    "box6": (0.1, 16, 1e-2),                  # 17 k triangles with uv, emissive triangles, reverse = 3 (splats: float atomics)
+    "cornell-box-spheres": (0.12, 16, 2e-3),  # LTC Beckmann + dielectric spheres (may_leak), areal lights
+}
+
+
+def scene_fixture(name, **kw):
+    from rgk_amd.workloads import SceneFixture
+    return SceneFixture(os.path.join(ROOT, "tests", "golden", "scene_%s.npz" % name), **kw)
+
+
+@pytest.mark.parametrize("name", sorted(REFERENCE_SCENES))
+def test_reference_scene_closest_hit(rd, oracle, name):
+    wl = scene_fixture(name)
+    g, o = both(rd, oracle, wl)
+    i = o.info()
+    lo, hi = np.array(list(i.bbox_min)), np.array(list(i.bbox_max))
+    oo, dd = random_rays(np.random.default_rng(7), lo, hi, 200000)
+    # different triangle only inside the epsilon tie band (cube3 has coincident faces: ~1 % of rays tie), never unexplained
+    assert check_closest(g, o, make_rays(oo, dd), i.epsilon, max_unexplained=5e-5) > 0.98
+
+
+@pytest.mark.parametrize("name", sorted(REFERENCE_SCENES))
+def test_reference_scene_image_parity(rd, oracle, name):
+    scale, spp, bound = REFERENCE_SCENES[name]
+    wl = scene_fixture(name, scale=scale, spp=spp)
+    img, ref, kg, ko = render_both(rd, oracle, wl)
+    rel, within = image_metrics(img, ref, wl.clamp, wl.multisample)
+    assert np.isfinite(img).all() and ref.max() > 0
+    assert rel <= bound, (name, rel, within)
+    assert abs(int(kg.path_rays) - int(ko.path_rays)) <= 2e-3 * ko.path_rays
+
+
 # ----------------------------------------------------------------------- whole path: images
 def render_both(rd, oracle, wl, prm=None, g=None, o=None):
     if g is None:

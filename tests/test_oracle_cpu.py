@@ -387,3 +387,34 @@ def test_stratified_and_halton_estimators_agree(oracle, cornell):
     n = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
     assert n(h, s1) < 2.0 * n(s2, s1)
     assert abs(h.mean() / s1.mean() - 1) < 0.05
+
+
+# ----------------------------------------------------------------------- scenes the reference ships complete
+REFERENCE_SCENES = ["rubiks-bump", "cube3", "box6", "cornell-box-spheres"]
+
+
+@pytest.mark.parametrize("name", REFERENCE_SCENES)
+def test_reference_scene_fixture_renders_and_regenerates(oracle, name):
+    """tests/golden/scene_<name>.npz = the flat arrays the loader hands to Scene for scenes/<name>.json.
+    The oracle renders it (finite, non-black, every path counted); where the reference tree is present the
+    fixture is rebuilt from its config / mesh / texture files and must come out identical."""
+    from rgk_amd.workloads import SceneFixture
+    path = os.path.join(ROOT, "tests", "golden", "scene_%s.npz" % name)
+    wl = SceneFixture(path, scale=0.06, spp=4)
+    o = oracle.OracleScene(wl.builder.to_desc())
+    acc, cnt, k = o.render_round(wl.camera, wl.params(), oracle.generate_task_list(wl.xres, wl.yres))
+    assert np.isfinite(acc).all() and acc.max() > 0 and (cnt == wl.multisample).all()
+    assert k.paths == wl.xres * wl.yres * wl.multisample
+    ref = "/root/reference/scenes/%s.json" % name
+    if not os.path.exists(ref):
+        return
+    from rgk_amd.config import Config
+    sb = Config(ref).build_scene()
+    sb.finalize()
+    for a in ("V", "N", "T", "UV", "F", "FM"):
+        assert np.array_equal(getattr(sb, a), getattr(wl.builder, a)), a
+    assert len(sb.textures) == len(wl.builder.textures)
+    for t0, t1 in zip(sb.textures, wl.builder.textures):
+        assert t0["kind"] == t1["kind"]
+        if t0["kind"] != 0:
+            assert np.array_equal(t0["data"], t1["data"])

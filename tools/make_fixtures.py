@@ -8,6 +8,10 @@ needs /root/reference).  Fixtures are DATA: inputs and expected outputs.
   rgk_amd/data/cornell_scene.npz  the flat arrays ConfigJSON::Install* would hand to Scene for
                      scenes/cornell-box.json (built by rgk_amd.config from the reference's
                      config file), plus camera / render parameters.
+  scene_<name>.npz   the same for the other scenes the reference ships complete (mesh + textures):
+                     rubiks-bump (PNG texture + bump map, point light), cube3 (8966 faces, global
+                     ltc_beckmann override, sphere light), box6 (17 k triangles with uv, emissive
+                     triangles, reverse = 3), cornell-box-spheres (LTC Beckmann + dielectric spheres).
 """
 import os
 import subprocess
@@ -45,7 +49,31 @@ def cornell():
     print("cornell_scene.npz", len(sb.V), "vertices", len(sb.F), "triangles")
 
 
+# scenes the reference ships COMPLETE (config + mesh + textures), converted to the flat arrays its loader
+# would hand to Scene; the .npz holds data only (geometry, decoded texel bytes, scalars)
+REFERENCE_SCENES = ["rubiks-bump", "cube3", "box6", "cornell-box-spheres"]
+
+
+def reference_scene(name):
+    from rgk_amd.config import Config
+    cfg = Config(os.path.join(REF, "scenes", name + ".json"))
+    sb = cfg.build_scene()
+    cfg.get_camera()
+    cam = cfg.root.d["camera"]
+    extra = dict(camera=dict(pos=cam["position"], lookat=cam["lookat"], up=cam.get("upvector", [0.0, 1.0, 0.0]),
+                             fov=cam.get("fov"), focal=cam.get("focal"), focus_plane=cam.get("focus-plane", 1.0),
+                             lens_size=cam.get("lens-size", 0.0)),
+                 xres=cfg.xres, yres=cfg.yres, multisample=cfg.multisample, depth=cfg.recursion_level,
+                 clamp=float(cfg.clamp), russian=float(cfg.russian), bumpscale=float(cfg.bumpmap_scale),
+                 reverse=cfg.reverse, source="scenes/%s.json" % name)
+    out = os.path.join(GOLD, "scene_%s.npz" % name)
+    sb.save_npz(out, extra)
+    print(os.path.basename(out), len(sb.V), "vertices", len(sb.F), "triangles", os.path.getsize(out) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     halton()
     cornell()
+    for n in REFERENCE_SCENES:
+        reference_scene(n)
