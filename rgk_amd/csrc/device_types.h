@@ -9,6 +9,7 @@
 
 #define RGK_NODE_BYTES 64 // QNode
 #define RGK_TRI_BYTES 48  // TriIsect
+#define RGK_LTC_TABLE_BYTES (4096u * 32u)
 
 // Host-side intermediate of the build: binary node with both child boxes.  Children < 0 are
 // leaves: ~child = (first << 4) | (count - 1), `first` indexing TriIsect records in leaf order.
@@ -49,11 +50,11 @@ struct TriIsect {
 };
 
 // Everything shading needs about one triangle, gathered behind ONE index (the hit's triangle id):
-// 7 x 16 B, contiguous -- instead of an index record followed by six scattered vertex fetches.
+// 7 x 16 B (+ 16 B pad = one 128-byte line), contiguous -- instead of an index record followed by six scattered vertex fetches.
 //   {nA.xyz, uvA.x} {nB.xyz, uvA.y} {nC.xyz, uvB.x} {tA.xyz, uvB.y} {tB.xyz, uvC.x} {tC.xyz, uvC.y} {mat,-,-,-}
 struct TriShade {
     float q[6][4];
-    uint32_t mat, pad[3];
+    uint32_t mat, pad[7]; // padded to 128 B: one record = one cache line
 };
 
 // A texture as a material sees it, 16 B so it rides inside the material record (no second,
@@ -118,6 +119,7 @@ struct DevCamera {
 };
 
 struct DevScene {
+    const DevScene* self; // this record in device memory, for the out-of-line generic BxDF route (rgk_device.h)
     const QNode* nodes;
     const TriIsect* tris;
     const TriShade* tri_shade;
@@ -128,8 +130,7 @@ struct DevScene {
     const DevPointLight* pointlights;
     const DevArealLight* areal;
     const DevArealTri* areal_tris;
-    const float4* ltc_ggx;      // 4096 x {m0,m2,m4,m6}{amp,0,0,0}
-    const float4* ltc_beckmann;
+    const float4* ltc; // GGX table, then Beckmann: each 4096 x {m0,m2,m4,m6}{amp,0,0,0} = RGK_LTC_TABLE_BYTES
     const DevHaltonDim* hdims;
     const uint16_t* hperm;
     uint32_t n_pointlights, n_areal;

@@ -11,6 +11,43 @@
 
 #define RGK_PI_F 3.14159265358979323846264338327950288f
 
+// ------------------------------------------------------------------ scene-table loads
+// Pointers that reach a kernel inside a by-value struct (DevScene, PassParams) are generic to the compiler: it
+// emits flat_load with a 64-bit address pair per access.  The scene tables are global memory and far below 4 GiB
+// each, so they are read as (uniform base in SGPRs) + (ONE 32-bit byte offset in a VGPR), address space 1:
+// `global_load ... v_off, s[base]`.  The shade kernels are register-bound; this is where their spills came from.
+#define RGK_GLOBAL __attribute__((address_space(1)))
+typedef float rgk_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ const RGK_GLOBAL char* gld_addr(const void* base, uint32_t byte_off) {
+    const RGK_GLOBAL char* p = (const RGK_GLOBAL char*)base + byte_off;
+    return p;
+}
+__device__ __forceinline__ uint32_t gld_u32(const void* base, uint32_t byte_off) { return *reinterpret_cast<const RGK_GLOBAL uint32_t*>(gld_addr(base, byte_off)); }
+__device__ __forceinline__ uint32_t gld_u16(const void* base, uint32_t byte_off) { return *reinterpret_cast<const RGK_GLOBAL uint16_t*>(gld_addr(base, byte_off)); }
+__device__ __forceinline__ float gld_f32(const void* base, uint32_t byte_off) { return *reinterpret_cast<const RGK_GLOBAL float*>(gld_addr(base, byte_off)); }
+__device__ __forceinline__ float4 gld_f4(const void* base, uint32_t byte_off) {
+    const rgk_f4v v = *reinterpret_cast<const RGK_GLOBAL rgk_f4v*>(gld_addr(base, byte_off));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+template <typename T>
+__device__ __forceinline__ T gld_rec(const void* base, uint32_t byte_off) { // a whole record (a multiple of 4 bytes)
+    static_assert(sizeof(T) % 4 == 0, "record size");
+    T out;
+    uint32_t* o = reinterpret_cast<uint32_t*>(&out);
+#pragma unroll
+    for (uint32_t k = 0; k < sizeof(T) / 4; k++) o[k] = gld_u32(base, byte_off + 4u * k);
+    return out;
+}
+// per-slot path state can exceed 4 GiB: 64-bit offset, still address space 1
+__device__ __forceinline__ float4 gld_f4_wide(const void* base, size_t index) {
+    const rgk_f4v v = reinterpret_cast<const RGK_GLOBAL rgk_f4v*>((const RGK_GLOBAL char*)base)[index];
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void gst_f4_wide(void* base, size_t index, float4 v) {
+    const rgk_f4v w = {v.x, v.y, v.z, v.w};
+    reinterpret_cast<RGK_GLOBAL rgk_f4v*>((RGK_GLOBAL char*)base)[index] = w;
+}
+
 struct f3 {
     float x, y, z;
 };
@@ -56,7 +93,7 @@ __device__ __forceinline__ quatf angle_axis(float a, f3 axis) {
     return r;
 }
 // RotationBetweenVectors, reference src/glm.cpp:3-33
-__device__ inline quatf rotation_between(f3 start, f3 dest) {
+__device__ __forceinline__ quatf rotation_between(f3 start, f3 dest) {
     start = norm3(start);
     dest = norm3(dest);
     float cosTheta = dot3(start, dest);
@@ -73,7 +110,7 @@ __device__ inline quatf rotation_between(f3 start, f3 dest) {
     return r;
 }
 // RotationFromY, reference src/glm.cpp:35-59
-__device__ inline quatf rotation_from_y(f3 dest) {
+__device__ __forceinline__ quatf rotation_from_y(f3 dest) {
     dest = norm3(dest);
     float cosTheta = dest.y;
     if (cosTheta < -1 + 0.00001f) return angle_axis(RGK_PI_F, mk3(1.0f, 0.0f, 0.0f));
@@ -95,18 +132,18 @@ __device__ __forceinline__ float u01(uint32_t h) { return (float)(h >> 8) * (1.0
 // external/halton_sampler.h:627-889 (dispatch), :1418-.. (halton2, halton3, ...).
 // Digit walk with a per-base Faure permutation and a multiply-high division instead of
 // the header's 256 generated functions and grouped-digit tables; bit-identical results.
-__device__ inline float halton_raw(const DevScene& sc, uint32_t hdim, uint32_t index) {
+__device__ __forceinline__ float halton_raw(const DevScene& sc, uint32_t hdim, uint32_t index) {
     if (hdim == 0) {
         uint32_t u = 0x3f800000u | (__brev(index) >> 9);
         return __uint_as_float(u) - 1.f;
     }
-    const DevHaltonDim hd = sc.hdims[hdim];
+    const DevHaltonDim hd = gld_rec<DevHaltonDim>(sc.hdims, hdim * (uint32_t)sizeof(DevHaltonDim));
     uint32_t acc = 0, j = 0;
     while (index != 0 && j < hd.digits) {
         uint32_t t = __umulhi(hd.magic, index);
         uint32_t q = (t + ((index - t) >> 1)) >> hd.shift;
         uint32_t r = index - q * hd.base;
-        acc = acc * hd.base + (uint32_t)sc.hperm[hd.perm_off + r];
+        acc = acc * hd.base + gld_u16(sc.hperm, (hd.perm_off + r) << 1);
         index = q;
         j++;
     }
@@ -114,7 +151,7 @@ __device__ inline float halton_raw(const DevScene& sc, uint32_t hdim, uint32_t i
     return (float)acc * hd.scale;
 }
 __device__ __forceinline__ uint32_t hdim_key(uint32_t hdim) { return mix32(hdim * 0x9e3779b9u + 0x85ebca6bu); }
-__device__ inline float halton_cp(const DevScene& sc, uint32_t seed, uint32_t index, uint32_t hdim) {
+__device__ __forceinline__ float halton_cp(const DevScene& sc, uint32_t seed, uint32_t index, uint32_t hdim) {
     if (hdim >= 192) return u01(mix32(mix32(seed ^ hdim_key(hdim)) + index * 0xc2b2ae35u));
     float u = halton_raw(sc, hdim, index) + u01(mix32(seed ^ hdim_key(hdim)));
     if (u >= 1.0f) u -= 1.0f;
@@ -122,13 +159,13 @@ __device__ inline float halton_cp(const DevScene& sc, uint32_t seed, uint32_t in
 }
 // Sampler::Get2D / Get1D for logical dimension k of sample `index` (reference
 // src/sampler.cpp:26-36: separate 1-D and 2-D counters; 64 table dimensions each)
-__device__ inline float2 sample2d(const DevScene& sc, uint32_t seed, uint32_t index, uint32_t k) {
+__device__ __forceinline__ float2 sample2d(const DevScene& sc, uint32_t seed, uint32_t index, uint32_t k) {
     uint32_t d = k < 64 ? 3 * k : 192 + 3 * (k - 64);
     float x = halton_cp(sc, seed, index, d);
     float y = halton_cp(sc, seed, index, d + 1);
     return make_float2(x, y);
 }
-__device__ inline float sample1d(const DevScene& sc, uint32_t seed, uint32_t index, uint32_t k) {
+__device__ __forceinline__ float sample1d(const DevScene& sc, uint32_t seed, uint32_t index, uint32_t k) {
     return halton_cp(sc, seed, index, k < 64 ? 3 * k + 2 : 192 + 3 * (k - 64) + 2);
 }
 // The raw Halton value depends on (dimension, sample index) only, not on the pixel: a round
@@ -155,22 +192,22 @@ __device__ __forceinline__ float sample1d_t(const SamplerTab& tb, uint32_t seed,
 }
 
 // ------------------------------------------------------------------ random_utils.hpp:12-73
-__device__ inline float2 disc_uniform(float2 s) {
+__device__ __forceinline__ float2 disc_uniform(float2 s) {
     float r = sqrtf(s.x);
     float a = (float)((double)(s.y * 2.0f) * 3.14159265358979323846);
     return make_float2(r * sinf(a), r * cosf(a));
 }
-__device__ inline f3 hemisphere_cosine_z(float2 s) {
+__device__ __forceinline__ f3 hemisphere_cosine_z(float2 s) {
     float2 p = disc_uniform(s);
     float z = sqrtf(fmaxf(0.00001f, 1 - p.x * p.x - p.y * p.y));
     return mk3(p.x, p.y, z);
 }
-__device__ inline f3 hemisphere_cosine_y(float2 s) {
+__device__ __forceinline__ f3 hemisphere_cosine_y(float2 s) {
     float2 p = disc_uniform(s);
     float y = sqrtf(fmaxf(0.00001f, 1 - p.x * p.x - p.y * p.y));
     return mk3(p.x, y, p.y);
 }
-__device__ inline f3 sphere_uniform(float2 s) {
+__device__ __forceinline__ f3 sphere_uniform(float2 s) {
     float z = s.x * 2.0f - 1.0f;
     float a = (float)((double)s.y * 6.283185);
     float r = sqrtf(1 - z * z);
@@ -186,20 +223,25 @@ __device__ __forceinline__ bool decide_and_rescale(float& sample, float probabil
 
 // ------------------------------------------------------------------ textures (a14)
 __device__ __forceinline__ float glm_repeat(float x) { return x - floorf(x); }
-__device__ __forceinline__ f3 texel_at(const DevScene& sc, const TexRef t, int idx) {
-    if (t.kind == RGK_TEX_RGB8) { // the bytes the 8-bit loaders keep + the table that makes them the reference's floats
-        const uint32_t w = sc.texels8[t.b + (uint32_t)idx];
-        const float* lut = sc.luts + t.c;
-        return mk3(lut[w & 0xffu], lut[(w >> 8) & 0xffu], lut[(w >> 16) & 0xffu]);
+__device__ __forceinline__ uint32_t tex_kind(const TexRef t) { return t.kind; }
+__device__ __forceinline__ uint32_t tex_row(const TexRef t, int y) { return (uint32_t)y * (t.a & 0xffffu); }
+__device__ __forceinline__ uint32_t tex_col(const TexRef t, int x) { return (uint32_t)x; }
+// (Texels in 8 x 4 tiles of one 128-byte line each, so that a bilinear footprint mostly touches one line, were
+// measured: no change in the shade kernel's time, 134.5 vs 135.8 ms.  Row-major, like the reference.)
+__device__ __forceinline__ f3 texel_at(const DevScene& sc, const TexRef t, uint32_t idx) { // idx = tex_row + tex_col
+    if (tex_kind(t) == RGK_TEX_RGB8) { // the bytes the 8-bit loaders keep + the table that makes them the reference's floats
+        const uint32_t w = gld_u32(sc.texels8, (t.b + idx) << 2);
+        const uint32_t lut = t.c << 2;
+        return mk3(gld_f32(sc.luts, lut + ((w & 0xffu) << 2)), gld_f32(sc.luts, lut + ((w >> 6) & 0x3fcu)), gld_f32(sc.luts, lut + ((w >> 14) & 0x3fcu)));
     }
-    const float4 v = sc.texels[t.b + (uint32_t)idx];
+    const float4 v = gld_f4(sc.texels, (t.b + idx) << 4);
     return mk3(v.x, v.y, v.z);
 }
 // ReadableTexture::GetPixelInterpolated, reference src/texture.cpp:35-77 (FileTexture) and
 // src/texture.hpp:64-80 (Solid / Empty)
-__device__ inline f3 tex_get(const DevScene& sc, const TexRef t, float2 uv) {
-    if (t.kind == RGK_TEXREF_NONE) return mk3(0.f, 0.f, 0.f);
-    if (t.kind == RGK_TEX_SOLID) return mk3(__uint_as_float(t.a), __uint_as_float(t.b), __uint_as_float(t.c));
+__device__ __forceinline__ f3 tex_get(const DevScene& sc, const TexRef t, float2 uv) {
+    if (tex_kind(t) == RGK_TEXREF_NONE) return mk3(0.f, 0.f, 0.f);
+    if (tex_kind(t) == RGK_TEX_SOLID) return mk3(__uint_as_float(t.a), __uint_as_float(t.b), __uint_as_float(t.c));
     const int xsize = (int)(t.a & 0xffffu), ysize = (int)(t.a >> 16);
     float x = glm_repeat(uv.x) * xsize - 0.5f;
     float y = glm_repeat(uv.y) * ysize - 0.5f;
@@ -210,8 +252,9 @@ __device__ inline f3 tex_get(const DevScene& sc, const TexRef t, float2 uv) {
     int iy1 = (iy0 != ysize - 1) ? iy0 + 1 : iy0;
     if (ix0 == -1) ix0 = 0;
     if (iy0 == -1) iy0 = 0;
-    f3 c00 = texel_at(sc, t, iy0 * xsize + ix0), c01 = texel_at(sc, t, iy0 * xsize + ix1);
-    f3 c10 = texel_at(sc, t, iy1 * xsize + ix0), c11 = texel_at(sc, t, iy1 * xsize + ix1);
+    const uint32_t r0 = tex_row(t, iy0), r1 = tex_row(t, iy1), k0 = tex_col(t, ix0), k1 = tex_col(t, ix1);
+    f3 c00 = texel_at(sc, t, r0 + k0), c01 = texel_at(sc, t, r0 + k1);
+    f3 c10 = texel_at(sc, t, r1 + k0), c11 = texel_at(sc, t, r1 + k1);
     fy = 1.0f - fy;
     fx = 1.0f - fx;
     f3 c0s = fx * c00 + (1.0f - fx) * c01;
@@ -219,9 +262,9 @@ __device__ inline f3 tex_get(const DevScene& sc, const TexRef t, float2 uv) {
     return fy * c0s + (1.0f - fy) * c1s;
 }
 // GetSlopeRight / GetSlopeBottom, reference src/texture.cpp:79-102
-__device__ inline void tex_slopes(const DevScene& sc, const TexRef t, float2 uv, float& right, float& bottom) {
+__device__ __forceinline__ void tex_slopes(const DevScene& sc, const TexRef t, float2 uv, float& right, float& bottom) {
     right = 0.f; bottom = 0.f;
-    if (t.kind != RGK_TEX_RGB32F && t.kind != RGK_TEX_RGB8) return;
+    if (tex_kind(t) != RGK_TEX_RGB32F && tex_kind(t) != RGK_TEX_RGB8) return;
     const int xsize = (int)(t.a & 0xffffu), ysize = (int)(t.a >> 16);
     int x = (int)(glm_repeat(uv.x) * xsize - 0.5f);
     int y = (int)(glm_repeat(uv.y) * ysize - 0.5f);
@@ -229,9 +272,10 @@ __device__ inline void tex_slopes(const DevScene& sc, const TexRef t, float2 uv,
     int y2 = (y != ysize - 1) ? y + 1 : y;
     if (x == -1) x = 0;
     if (y == -1) y = 0;
-    f3 here = texel_at(sc, t, y * xsize + x);
-    f3 tr = texel_at(sc, t, y * xsize + x2);
-    f3 tb = texel_at(sc, t, y2 * xsize + x);
+    const uint32_t r0 = tex_row(t, y), k0 = tex_col(t, x);
+    f3 here = texel_at(sc, t, r0 + k0);
+    f3 tr = texel_at(sc, t, r0 + tex_col(t, x2));
+    f3 tb = texel_at(sc, t, tex_row(t, y2) + k0);
     float a = (here.x + here.y + here.z) / 3;
     right = a - (tr.x + tr.y + tr.z) / 3;
     bottom = a - (tb.x + tb.y + tb.z) / 3;
@@ -244,7 +288,7 @@ struct LtcM {
     float m0, m2, m4, m6, m8, amp;
 };
 // LTC::get_bilinear, reference src/LTC/ltc.cpp:20-57.  Table entry = {m0,m2,m4,m6}{amp,-,-,-}.
-__device__ inline LtcM ltc_bilinear(const float4* tab, float theta, float alpha) {
+__device__ __forceinline__ LtcM ltc_bilinear(const void* ltc, uint32_t tab, float theta, float alpha) { // tab: byte offset of the table in `ltc`
     float t = fmaxf(0.0f, fminf(1.0f, theta / (0.5f * 3.14159f)));
     float a = fmaxf(0.0f, fminf(1.0f, sqrtf(alpha)));
     if (t >= 1.0f) t = 0.999f;
@@ -252,9 +296,10 @@ __device__ inline LtcM ltc_bilinear(const float4* tab, float theta, float alpha)
     const int s = 63;
     int t1 = (int)floorf(t * s), t2 = t1 + 1;
     int a1 = (int)floorf(a * s), a2 = a1 + 1;
-    const float4 m11 = tab[2 * (a1 + t1 * 64)], m12 = tab[2 * (a2 + t1 * 64)], m21 = tab[2 * (a1 + t2 * 64)], m22 = tab[2 * (a2 + t2 * 64)];
-    const float p11 = tab[2 * (a1 + t1 * 64) + 1].x, p12 = tab[2 * (a2 + t1 * 64) + 1].x, p21 = tab[2 * (a1 + t2 * 64) + 1].x,
-                p22 = tab[2 * (a2 + t2 * 64) + 1].x;
+    const uint32_t o11 = tab + ((uint32_t)(a1 + t1 * 64) << 5), o12 = tab + ((uint32_t)(a2 + t1 * 64) << 5);
+    const uint32_t o21 = tab + ((uint32_t)(a1 + t2 * 64) << 5), o22 = tab + ((uint32_t)(a2 + t2 * 64) << 5);
+    const float4 m11 = gld_f4(ltc, o11), m12 = gld_f4(ltc, o12), m21 = gld_f4(ltc, o21), m22 = gld_f4(ltc, o22);
+    const float p11 = gld_f32(ltc, o11 + 16u), p12 = gld_f32(ltc, o12 + 16u), p21 = gld_f32(ltc, o21 + 16u), p22 = gld_f32(ltc, o22 + 16u);
     float dt1 = t * s - t1, dt2 = t2 - t * s, da1 = a * s - a1, da2 = a2 - a * s;
 #define RGK_BIL(e11, e12, e21, e22) ((e11) * dt2 * da2 + (e12) * dt2 * da1 + (e21) * dt1 * da2 + (e22) * dt1 * da1)
     LtcM r;
@@ -272,7 +317,7 @@ __device__ __forceinline__ float ltc_theta(f3 B) { return glm_angle(B, mk3(0.f, 
 // mat*vec with the structural zeros of M and of the N = +Z frame folded in: every surviving
 // product and sum keeps its place and order in glm's cofactor expressions (x*0 = +-0 and
 // x + +-0 = x for finite x), so the value is bit-identical to the general formulas of the oracle.
-__device__ inline float ltc_pdf_M(const LtcM& M, f3 A, f3 B) {
+__device__ __forceinline__ float ltc_pdf_M(const LtcM& M, f3 A, f3 B) {
     // rotate = mat3((B.x,B.y,0), (-B.y,B.x,0), (0,0,1)); A3 = inverse(rotate) * A
     float det = B.x * B.x + B.y * B.y;
     float ood = 1.0f / det;
@@ -294,18 +339,18 @@ __device__ inline float ltc_pdf_M(const LtcM& M, f3 A, f3 B) {
 }
 // LTC::GetRandom(ltc, N=+Z, Vi, roughness, rand_hscos), reference src/LTC/ltc.cpp:113-143, given
 // M interpolated at max(theta, pi/4)
-__device__ inline f3 ltc_random_M(const LtcM& M, f3 Vi, f3 rnd) {
+__device__ __forceinline__ f3 ltc_random_M(const LtcM& M, f3 Vi, f3 rnd) {
     f3 s = mk3(M.m0 * rnd.x + M.m6 * rnd.z, M.m4 * rnd.y, M.m2 * rnd.x + M.m8 * rnd.z);
     if (s.z < 0.0001f) s.z = 0.0001f;
     // rotate * s, rotate = mat3((Vi.x,Vi.y,0), (-Vi.y,Vi.x,0), (0,0,1))
     f3 r = mk3(Vi.x * s.x + (-Vi.y) * s.y, Vi.y * s.x + Vi.x * s.y, s.z);
     return norm3(r);
 }
-__device__ inline float ltc_pdf(const float4* tab, f3 A, f3 B, float alpha) {
-    return ltc_pdf_M(ltc_bilinear(tab, ltc_theta(B), alpha), A, B);
+__device__ __forceinline__ float ltc_pdf(const void* ltc, uint32_t tab, f3 A, f3 B, float alpha) {
+    return ltc_pdf_M(ltc_bilinear(ltc, tab, ltc_theta(B), alpha), A, B);
 }
-__device__ inline f3 ltc_random(const float4* tab, f3 Vi, float roughness, f3 rnd) {
-    return ltc_random_M(ltc_bilinear(tab, fmaxf(ltc_theta(Vi), RGK_PI_F / 4.0f), roughness), Vi, rnd);
+__device__ __forceinline__ f3 ltc_random(const void* ltc, uint32_t tab, f3 Vi, float roughness, f3 rnd) {
+    return ltc_random_M(ltc_bilinear(ltc, tab, fmaxf(ltc_theta(Vi), RGK_PI_F / 4.0f), roughness), Vi, rnd);
 }
 
 // ------------------------------------------------------------------ BxDFs (a11)
@@ -352,16 +397,16 @@ __device__ inline f3 bxdf_value_leaf(const DevScene& sc, const DevMaterial& m, f
     case RGK_BXDF_LTC_BECKMANN:
     case RGK_BXDF_LTC_GGX: {
         if (Vi.z <= 0 || Vr.z <= 0) return zero;
-        const float4* tab = (m.kind == RGK_BXDF_LTC_GGX) ? sc.ltc_ggx : sc.ltc_beckmann;
-        return tex_get(sc, m.t_color, uv) * ltc_pdf(tab, Vi, Vr, m.roughness);
+        const uint32_t tab = (m.kind == RGK_BXDF_LTC_GGX) ? 0u : RGK_LTC_TABLE_BYTES; // GGX table, then Beckmann, in one buffer
+        return tex_get(sc, m.t_color, uv) * ltc_pdf(sc.ltc, tab, Vi, Vr, m.roughness);
     }
     case RGK_BXDF_LTC_BECKMANN_DIFFUSE:
     case RGK_BXDF_LTC_GGX_DIFFUSE: {
         if (Vi.z <= 0 || Vr.z <= 0) return zero;
-        const float4* tab = (m.kind == RGK_BXDF_LTC_GGX_DIFFUSE) ? sc.ltc_ggx : sc.ltc_beckmann;
+        const uint32_t tab = (m.kind == RGK_BXDF_LTC_GGX_DIFFUSE) ? 0u : RGK_LTC_TABLE_BYTES; // GGX table, then Beckmann, in one buffer
         f3 diff = tex_get(sc, m.t_diffuse, uv);
         f3 spec = tex_get(sc, m.t_color, uv);
-        return spec * ltc_pdf(tab, Vi, Vr, m.roughness) + diff / RGK_PI_F;
+        return spec * ltc_pdf(sc.ltc, tab, Vi, Vr, m.roughness) + diff / RGK_PI_F;
     }
     default: return zero;
     }
@@ -369,17 +414,17 @@ __device__ inline f3 bxdf_value_leaf(const DevScene& sc, const DevMaterial& m, f
 // BxDFMix::value recurses once per level (reference bxdf.cpp:235-239); the device walks an
 // explicit stack so nested mixes up to 4 deep are evaluated without recursion.
 __device__ inline f3 bxdf_value(const DevScene& sc, int mat, f3 Vi, f3 Vr, float2 uv) {
-    const DevMaterial m = sc.materials[mat];
+    const DevMaterial m = gld_rec<DevMaterial>(sc.materials, mat * (uint32_t)sizeof(DevMaterial));
     if (m.kind != RGK_BXDF_MIX) return bxdf_value_leaf(sc, m, Vi, Vr, uv);
     // s1*amt1 + s2*(1-amt1) with one nested level on either side
     f3 s[2];
     const int ch[2] = {m.mix_m1, m.mix_m2};
     for (int k = 0; k < 2; k++) {
-        const DevMaterial c = sc.materials[ch[k]];
+        const DevMaterial c = gld_rec<DevMaterial>(sc.materials, ch[k] * (uint32_t)sizeof(DevMaterial));
         if (c.kind != RGK_BXDF_MIX) s[k] = bxdf_value_leaf(sc, c, Vi, Vr, uv);
         else {
-            const DevMaterial c1 = sc.materials[c.mix_m1];
-            const DevMaterial c2 = sc.materials[c.mix_m2];
+            const DevMaterial c1 = gld_rec<DevMaterial>(sc.materials, c.mix_m1 * (uint32_t)sizeof(DevMaterial));
+            const DevMaterial c2 = gld_rec<DevMaterial>(sc.materials, c.mix_m2 * (uint32_t)sizeof(DevMaterial));
             f3 v1 = (c1.kind == RGK_BXDF_MIX) ? mk3(0.f, 0.f, 0.f) : bxdf_value_leaf(sc, c1, Vi, Vr, uv);
             f3 v2 = (c2.kind == RGK_BXDF_MIX) ? mk3(0.f, 0.f, 0.f) : bxdf_value_leaf(sc, c2, Vi, Vr, uv);
             s[k] = v1 * c.amount + v2 * (1.0f - c.amount);
@@ -390,9 +435,9 @@ __device__ inline f3 bxdf_value(const DevScene& sc, int mat, f3 Vi, f3 Vr, float
 
 // BxDF::sample, reference src/bxdf/bxdf.cpp:197-204,241-249,272-276,378-408,419-423, bxdf.hpp:115-159
 __device__ inline void bxdf_sample(const DevScene& sc, int mat, f3 Vi, float2 uv, float2 u, f3& dir, f3& weight, bool& may_leak) {
-    DevMaterial m = sc.materials[mat];
+    DevMaterial m = gld_rec<DevMaterial>(sc.materials, mat * (uint32_t)sizeof(DevMaterial));
     for (int lvl = 0; lvl < 8 && m.kind == RGK_BXDF_MIX; lvl++) // BxDFMix::sample descends one side
-        m = sc.materials[decide_and_rescale(u.x, m.amount) ? m.mix_m1 : m.mix_m2];
+        m = gld_rec<DevMaterial>(sc.materials, (uint32_t)(decide_and_rescale(u.x, m.amount) ? m.mix_m1 : m.mix_m2) * (uint32_t)sizeof(DevMaterial));
     may_leak = false;
     const f3 zero = mk3(0.f, 0.f, 0.f);
     switch (m.kind) {
@@ -423,15 +468,15 @@ __device__ inline void bxdf_sample(const DevScene& sc, int mat, f3 Vi, float2 uv
         return;
     case RGK_BXDF_LTC_BECKMANN:
     case RGK_BXDF_LTC_GGX: {
-        const float4* tab = (m.kind == RGK_BXDF_LTC_GGX) ? sc.ltc_ggx : sc.ltc_beckmann;
-        f3 v = ltc_random(tab, Vi, m.roughness, hemisphere_cosine_z(u));
+        const uint32_t tab = (m.kind == RGK_BXDF_LTC_GGX) ? 0u : RGK_LTC_TABLE_BYTES; // GGX table, then Beckmann, in one buffer
+        f3 v = ltc_random(sc.ltc, tab, Vi, m.roughness, hemisphere_cosine_z(u));
         dir = v;
         weight = (v.z <= 0) ? zero : tex_get(sc, m.t_color, uv);
         return;
     }
     case RGK_BXDF_LTC_BECKMANN_DIFFUSE:
     case RGK_BXDF_LTC_GGX_DIFFUSE: {
-        const float4* tab = (m.kind == RGK_BXDF_LTC_GGX_DIFFUSE) ? sc.ltc_ggx : sc.ltc_beckmann;
+        const uint32_t tab = (m.kind == RGK_BXDF_LTC_GGX_DIFFUSE) ? 0u : RGK_LTC_TABLE_BYTES; // GGX table, then Beckmann, in one buffer
         f3 diff = tex_get(sc, m.t_diffuse, uv);
         f3 spec = tex_get(sc, m.t_color, uv);
         float dp = diff.x + diff.y + diff.z, sp = spec.x + spec.y + spec.z;
@@ -442,7 +487,7 @@ __device__ inline void bxdf_sample(const DevScene& sc, int mat, f3 Vi, float2 uv
             weight = diff;
             return;
         }
-        f3 v = ltc_random(tab, Vi, m.roughness, hemisphere_cosine_z(u));
+        f3 v = ltc_random(sc.ltc, tab, Vi, m.roughness, hemisphere_cosine_z(u));
         dir = v;
         weight = (v.z <= 0) ? zero : spec;
         return;
@@ -451,6 +496,16 @@ __device__ inline void bxdf_sample(const DevScene& sc, int mat, f3 Vi, float2 uv
         dir = mk3(0.f, 1.f, 0.f);
         weight = zero;
     }
+}
+
+// The generic BxDF route (mirror, dielectric, transparent, mix) reads the scene through the device-resident copy
+// DevScene::self, and every function that takes the scene is force-inlined, so a kernel's by-value DevScene never
+// needs an address: its pointers stay in SGPRs instead of being copied to scratch at kernel entry and re-read from
+// there (which is what ONE out-of-line `const DevScene&` call used to cost).
+#define RGK_SLOW_ATTR __forceinline__ // measured: as an out-of-line call it costs the shade kernel 25 % (190 vs 153 ms per two rounds)
+__device__ RGK_SLOW_ATTR f3 bxdf_value_slow(const DevScene* gsc, int mat, f3 Vi, f3 Vr, float2 uv) { return bxdf_value(*gsc, mat, Vi, Vr, uv); }
+__device__ RGK_SLOW_ATTR void bxdf_sample_slow(const DevScene* gsc, int mat, f3 Vi, float2 uv, float2 u, f3& dir, f3& weight, bool& may_leak) {
+    bxdf_sample(*gsc, mat, Vi, uv, u, dir, weight, may_leak);
 }
 
 // Per-vertex material evaluation with everything `sample` and `value` share fetched once:
@@ -462,7 +517,8 @@ struct MatPrep {
     f3 diffc, colorc;
     LtcM Mv, Ms;
 };
-__device__ inline void mat_prepare(const DevScene& sc, const DevMaterial& m, float2 uv, f3 VrL, bool need_sample, MatPrep& e) {
+__device__ __forceinline__ bool mat_is_fast(uint32_t k) { return k == RGK_BXDF_DIFFUSE || k >= RGK_BXDF_LTC_BECKMANN; } // MatPrep::fast
+__device__ __forceinline__ void mat_prepare(const DevScene& sc, const DevMaterial& m, float2 uv, f3 VrL, bool need_sample, MatPrep& e) {
     e.fast = false;
     e.diffc = e.colorc = mk3(0.f, 0.f, 0.f);
     const uint32_t k = m.kind;
@@ -473,15 +529,17 @@ __device__ inline void mat_prepare(const DevScene& sc, const DevMaterial& m, flo
         e.fast = true;
         e.colorc = tex_get(sc, m.t_color, uv);
         if (k >= RGK_BXDF_LTC_BECKMANN_DIFFUSE) e.diffc = tex_get(sc, m.t_diffuse, uv);
-        const float4* tab = (k == RGK_BXDF_LTC_GGX || k == RGK_BXDF_LTC_GGX_DIFFUSE) ? sc.ltc_ggx : sc.ltc_beckmann;
+        const uint32_t tab = (k == RGK_BXDF_LTC_GGX || k == RGK_BXDF_LTC_GGX_DIFFUSE) ? 0u : RGK_LTC_TABLE_BYTES; // GGX table, then Beckmann, in one buffer
         const float theta = ltc_theta(VrL);
-        e.Mv = ltc_bilinear(tab, theta, m.roughness);
-        e.Ms = (theta >= RGK_PI_F / 4.0f || !need_sample) ? e.Mv : ltc_bilinear(tab, RGK_PI_F / 4.0f, m.roughness);
+        e.Mv = ltc_bilinear(sc.ltc, tab, theta, m.roughness);
+        e.Ms = (theta >= RGK_PI_F / 4.0f || !need_sample) ? e.Mv : ltc_bilinear(sc.ltc, tab, RGK_PI_F / 4.0f, m.roughness);
     }
 }
-__device__ inline void mat_sample(const DevScene& sc, int mat, const DevMaterial& m, const MatPrep& e, f3 VrL, float2 uv, float2 u,
+// GENERIC = false: the caller guarantees a fast-route material (the generic route is compiled out)
+template <bool GENERIC = true>
+__device__ __forceinline__ void mat_sample(const DevScene& sc, int mat, const DevMaterial& m, const MatPrep& e, f3 VrL, float2 uv, float2 u,
                                   f3& dir, f3& weight, bool& may_leak) {
-    if (!e.fast) { bxdf_sample(sc, mat, VrL, uv, u, dir, weight, may_leak); return; }
+    if (GENERIC && !e.fast) { bxdf_sample_slow(sc.self, mat, VrL, uv, u, dir, weight, may_leak); return; }
     may_leak = false;
     const f3 zero = mk3(0.f, 0.f, 0.f);
     bool lobe = m.kind != RGK_BXDF_DIFFUSE; // LTC lobe, unless the diffuse branch is chosen below
@@ -500,8 +558,9 @@ __device__ inline void mat_sample(const DevScene& sc, int mat, const DevMaterial
     dir = v;
     weight = (v.z <= 0) ? zero : e.colorc;
 }
-__device__ inline f3 mat_value(const DevScene& sc, int mat, const DevMaterial& m, const MatPrep& e, f3 ViL, f3 VrL, float2 uv) {
-    if (!e.fast) return bxdf_value(sc, mat, ViL, VrL, uv);
+template <bool GENERIC = true>
+__device__ __forceinline__ f3 mat_value(const DevScene& sc, int mat, const DevMaterial& m, const MatPrep& e, f3 ViL, f3 VrL, float2 uv) {
+    if (GENERIC && !e.fast) return bxdf_value_slow(sc.self, mat, ViL, VrL, uv);
     if (ViL.z <= 0 || VrL.z <= 0) return mk3(0.f, 0.f, 0.f);
     if (m.kind == RGK_BXDF_DIFFUSE) return e.diffc / RGK_PI_F;
     float pdf = ltc_pdf_M(e.Mv, ViL, VrL);
@@ -521,7 +580,7 @@ __device__ __forceinline__ float light_dir_factor(const DLight& l, f3 v) {
 }
 // Scene::GetRandomLight + ArealLight::GetRandomLight + Triangle::GetRandomPoint, reference
 // src/scene.cpp:686-745, src/primitives.cpp:61-73
-__device__ inline DLight random_light(const DevScene& sc, float2 choice, float light_sample, float2 tri_sample) {
+__device__ __forceinline__ DLight random_light(const DevScene& sc, float2 choice, float light_sample, float2 tri_sample) {
     DLight L;
     L.type = -1;
     L.pos = L.color = L.normal = mk3(0.f, 0.f, 0.f);
@@ -531,7 +590,7 @@ __device__ inline DLight random_light(const DevScene& sc, float2 choice, float l
     float q = choice.x * total_power;
     if (q < sc.total_point_power) {
         for (uint32_t i = 0; i < sc.n_pointlights; i++) {
-            const DevPointLight pl = sc.pointlights[i];
+            const DevPointLight pl = gld_rec<DevPointLight>(sc.pointlights, i * (uint32_t)sizeof(DevPointLight));
             q -= pl.intensity * 4.0f * RGK_PI_F;
             if (q <= 0.0f) {
                 L.type = 0;
@@ -545,12 +604,13 @@ __device__ inline DLight random_light(const DevScene& sc, float2 choice, float l
     }
     q = choice.y * sc.total_areal_power;
     for (uint32_t i = 0; i < sc.n_areal; i++) {
-        const DevArealLight al = sc.areal[i];
+        const DevArealLight al = gld_rec<DevArealLight>(sc.areal, i * (uint32_t)sizeof(DevArealLight));
         q -= al.power;
         if (q <= 0.0f) {
             float p = light_sample * al.total_area;
             for (uint32_t j = 0; j < al.count; j++) {
-                const DevArealTri* at = &sc.areal_tris[al.first + j];
+                const DevArealTri att = gld_rec<DevArealTri>(sc.areal_tris, (al.first + j) * (uint32_t)sizeof(DevArealTri));
+                const DevArealTri* at = &att;
                 p -= at->area;
                 if (p <= 0.0f) {
                     float2 r = tri_sample;
@@ -578,7 +638,7 @@ __device__ inline DLight random_light(const DevScene& sc, float2 choice, float l
 // 0x80000000 | areal-triangle index, or RGK_LIGHT_NONE.  Colour / normal / intensity are re-read
 // from the (tiny, cached) light tables.
 #define RGK_LIGHT_NONE 0x7fffffffu
-__device__ inline uint32_t light_code(const DevScene& sc, float2 choice, float light_sample, float2 tri_sample, f3& pos) {
+__device__ __forceinline__ uint32_t light_code(const DevScene& sc, float2 choice, float light_sample, float2 tri_sample, f3& pos) {
     DLight L = random_light(sc, choice, light_sample, tri_sample);
     pos = L.pos;
     if (L.type < 0) return RGK_LIGHT_NONE;
@@ -588,29 +648,32 @@ __device__ inline uint32_t light_code(const DevScene& sc, float2 choice, float l
     }
     return 0x80000000u | (uint32_t)L.index;
 }
-__device__ inline DLight light_from_code(const DevScene& sc, f3 pos, uint32_t code) {
+__device__ __forceinline__ DLight light_from_code(const DevScene& sc, f3 pos, uint32_t code) {
     DLight L;
     L.pos = pos;
     L.normal = L.color = mk3(0.f, 0.f, 0.f);
     L.intensity = 0.f; L.size = 0.f; L.index = 0;
     if (code == RGK_LIGHT_NONE) { L.type = -1; return L; }
     if (code & 0x80000000u) {
-        const DevArealTri* at = &sc.areal_tris[code & 0x7fffffffu];
-        const DevArealLight* al = &sc.areal[at->light];
+        const DevArealTri att = gld_rec<DevArealTri>(sc.areal_tris, (code & 0x7fffffffu) * (uint32_t)sizeof(DevArealTri));
+        const DevArealLight all = gld_rec<DevArealLight>(sc.areal, att.light * (uint32_t)sizeof(DevArealLight));
+        const DevArealTri* at = &att;
+        const DevArealLight* al = &all;
         L.type = 1;
         L.color = mk3(al->emission[0], al->emission[1], al->emission[2]);
         L.intensity = 1.0f;
         L.normal = mk3(at->normal_a[0], at->normal_a[1], at->normal_a[2]);
         return L;
     }
-    const DevPointLight* pl = &sc.pointlights[code];
+    const DevPointLight plv = gld_rec<DevPointLight>(sc.pointlights, code * (uint32_t)sizeof(DevPointLight));
+    const DevPointLight* pl = &plv;
     L.type = 0;
     L.color = mk3(pl->color[0], pl->color[1], pl->color[2]);
     L.intensity = pl->intensity; L.size = pl->size;
     return L;
 }
 // Scene::GetSkyboxRay, reference src/scene.cpp:748-763
-__device__ inline f3 skybox(const DevScene& sc, f3 direction) {
+__device__ __forceinline__ f3 skybox(const DevScene& sc, f3 direction) {
     if (sc.sky_mode == 0) return mk3(sc.sky_color[0], sc.sky_color[1], sc.sky_color[2]) * mk3(sc.sky_intensity, sc.sky_intensity, sc.sky_intensity);
     float alpha = asinf(direction.y);
     float beta = -atan2f(direction.x, direction.z);
@@ -635,12 +698,12 @@ struct Vertex {
 };
 __device__ __forceinline__ f3 clamp3(f3 v, float c) { return mk3(v.x > c ? c : v.x, v.y > c ? c : v.y, v.z > c ? c : v.z); }
 
-__device__ inline void surface_point(const DevScene& sc, float bumpmap_scale, f3 o, f3 d, float4 h, Vertex& v) {
+__device__ __forceinline__ void surface_point(const DevScene& sc, float bumpmap_scale, f3 o, f3 d, float4 h, Vertex& v) {
     const int tri = __float_as_int(h.w);
-    const float4* tsr = reinterpret_cast<const float4*>(sc.tri_shade) + 7 * (size_t)tri;
-    const float4 g0 = tsr[0], g1 = tsr[1], g2 = tsr[2];
-    v.mat_id = __float_as_uint(tsr[6].x);
-    v.mat = sc.materials[v.mat_id];
+    const uint32_t tsr = (uint32_t)tri * (uint32_t)sizeof(TriShade);
+    const float4 g0 = gld_f4(sc.tri_shade, tsr), g1 = gld_f4(sc.tri_shade, tsr + 16u), g2 = gld_f4(sc.tri_shade, tsr + 32u);
+    v.mat_id = gld_u32(sc.tri_shade, tsr + 96u);
+    v.mat = gld_rec<DevMaterial>(sc.materials, v.mat_id * (uint32_t)sizeof(DevMaterial));
     const float al = h.y, be = h.z;
     const float ia = 1.0f - al - be, ib = al, ic = be; // Intersection::a,b,c scene_intersect.cpp:280-283
     v.Vr = -d;
@@ -657,13 +720,13 @@ __device__ inline void surface_point(const DevScene& sc, float bumpmap_scale, f3
     v.faceN = v.lightN = faceN;
     if (!v.ok) return;
     faceN = norm3(faceN);
-    const float4 g3 = tsr[3], g4 = tsr[4], g5 = tsr[5];
+    const float4 g3 = gld_f4(sc.tri_shade, tsr + 48u), g4 = gld_f4(sc.tri_shade, tsr + 64u), g5 = gld_f4(sc.tri_shade, tsr + 80u);
     if (sc.has_texcoords) {
         v.uv.x = ia * g0.w + ib * g2.w + ic * g4.w;
         v.uv.y = ia * g1.w + ib * g3.w + ic * g5.w;
     }
     f3 lightN = faceN;
-    if (v.mat.t_bump.kind != RGK_TEXREF_NONE) { // bump, path_tracer.cpp:204-231
+    if (tex_kind(v.mat.t_bump) != RGK_TEXREF_NONE) { // bump, path_tracer.cpp:204-231
         float right, bottom;
         tex_slopes(sc, v.mat.t_bump, v.uv, right, bottom);
         f3 tangent = ia * mk3(g3.x, g3.y, g3.z) + ib * mk3(g4.x, g4.y, g4.z) + ic * mk3(g5.x, g5.y, g5.z);
@@ -682,7 +745,7 @@ __device__ inline void surface_point(const DevScene& sc, float bumpmap_scale, f3
 }
 
 // Camera::GetCoordsFromDirection, reference src/camera.cpp:48-83 (Q16: coordinates clamped to the frame)
-__device__ inline bool coords_from_direction(const DevCamera& cam, f3 dir, int& x, int& y) {
+__device__ __forceinline__ bool coords_from_direction(const DevCamera& cam, f3 dir, int& x, int& y) {
     const f3 N = mk3(cam.direction[0], cam.direction[1], cam.direction[2]);
     const f3 origin = mk3(cam.origin[0], cam.origin[1], cam.origin[2]);
     const f3 V = mk3(cam.viewscreen[0], cam.viewscreen[1], cam.viewscreen[2]);

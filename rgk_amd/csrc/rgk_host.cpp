@@ -300,7 +300,9 @@ struct rgk_scene {
     DevBuf<DevPointLight> pointlights;
     DevBuf<DevArealLight> areal;
     DevBuf<DevArealTri> areal_tris;
-    DevBuf<float4> ltc_ggx, ltc_beckmann;
+    DevBuf<float4> ltc;
+    DevBuf<DevScene> self;
+    DevBuf<uint32_t> generic; // queue indices left to the generic-BxDF shade launch // device-resident copy of `dev` (DevScene::self)
     DevBuf<DevHaltonDim> hdims;
     DevBuf<uint16_t> hperm;
     // workspace
@@ -321,8 +323,8 @@ struct rgk_scene {
         for (auto e : events) (void)hipEventDestroy(e);
         if (h_counters) (void)hipHostFree(h_counters);
         nodes.release(); tris.release(); tri_shade.release(); materials.release(); texels8.release(); luts.release();
-        texels.release(); pointlights.release(); areal.release(); areal_tris.release(); ltc_ggx.release();
-        ltc_beckmann.release(); hdims.release(); hperm.release();
+        texels.release(); pointlights.release(); areal.release(); areal_tris.release(); ltc.release(); self.release();
+        hdims.release(); hperm.release();
         for (int i = 0; i < 2; i++) { rayA[i].release(); rayB[i].release(); }
         hit.release(); thr.release(); tot.release(); shA.release(); shB.release(); shC.release(); pixsum.release();
         light.release(); htab.release(); lstart.release(); lv.release(); term.release(); vfin.release(); vemit.release();
@@ -354,6 +356,7 @@ int ensure_workspace(rgk_scene* s, size_t paths, uint32_t reverse = 0) {
         if (!rc) rc = s->vemit.alloc(paths);
     }
     if (!rc) rc = s->light.alloc(paths);
+    if (!rc) rc = s->generic.alloc(paths);
     if (!rc) rc = s->counters.alloc(2 * RGK_CNT_TOTAL); // [0]: camera phase, [1]: light sub-path phase
     if (!rc) rc = s->stats.alloc(8);
     if (rc) return rc;
@@ -550,7 +553,7 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
         max_depth = bb.max_depth;
         leaf_recs.reserve(bb.order.size());
         for (uint32_t t : bb.order) leaf_recs.push_back(recs[t]);
-        if (bb.order.size() >= (1u << 27)) return fail(RGK_ERR_UNSUPPORTED, "too many triangles for the leaf encoding");
+        if (bb.order.size() >= (1u << 25)) return fail(RGK_ERR_UNSUPPORTED, "too many triangles (32-bit byte offsets into the triangle tables: < 2^25)");
     }
     QbvhBuilder qb(nodes);
     qb.out.reserve(nodes.size() / 2 + 1);
@@ -588,7 +591,7 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
         } else if (t.kind == RGK_TEX_RGB8) {
             if (t.width > 65535 || t.height > 65535) return fail(RGK_ERR_UNSUPPORTED, "texture %u larger than 65535 texels on a side", i);
             const size_t n = (size_t)t.width * t.height;
-            if (pool8.size() + n >= (1ull << 32)) return fail(RGK_ERR_UNSUPPORTED, "texel pool exceeds 2^32 texels");
+            if (pool8.size() + n >= (1ull << 30)) return fail(RGK_ERR_UNSUPPORTED, "8-bit texel pool exceeds 2^30 texels"); // 32-bit byte offsets
             o.a = t.width | (t.height << 16);
             o.b = (uint32_t)pool8.size();
             o.c = 0;
@@ -603,7 +606,7 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
         } else {
             if (t.width > 65535 || t.height > 65535) return fail(RGK_ERR_UNSUPPORTED, "texture %u larger than 65535 texels on a side", i);
             const size_t n = (size_t)t.width * t.height;
-            if (pool.size() + n >= (1ull << 32)) return fail(RGK_ERR_UNSUPPORTED, "texel pool exceeds 2^32 texels");
+            if (pool.size() + n >= (1ull << 28)) return fail(RGK_ERR_UNSUPPORTED, "float texel pool exceeds 2^28 texels"); // 32-bit byte offsets
             o.a = t.width | (t.height << 16);
             o.b = (uint32_t)pool.size();
             pool.reserve(pool.size() + n);
@@ -680,29 +683,32 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
         (rc = s->luts.upload(luts)) || (rc = s->pointlights.upload(pls)) || (rc = s->areal.upload(als)) ||
         (rc = s->areal_tris.upload(ats)) || (rc = s->hdims.upload(hd)) || (rc = s->hperm.upload(hp)))
         return rc;
-    auto ltc_pack = [](const float* src) { // {m0,m2,m4,m6}{amp,0,0,0} per entry: two 16-byte loads
-        std::vector<float4> t(2 * 4096);
-        for (int k = 0; k < 4096; k++) {
-            t[2 * k] = make_float4(src[5 * k], src[5 * k + 1], src[5 * k + 2], src[5 * k + 3]);
-            t[2 * k + 1] = make_float4(src[5 * k + 4], 0.f, 0.f, 0.f);
-        }
-        return t;
-    };
-    if (d->ltc_ggx && (rc = s->ltc_ggx.upload(ltc_pack(d->ltc_ggx)))) return rc;
-    if (d->ltc_beckmann && (rc = s->ltc_beckmann.upload(ltc_pack(d->ltc_beckmann)))) return rc;
+    { // both LTC tables in one buffer, {m0,m2,m4,m6}{amp,0,0,0} per entry (two 16-byte loads): GGX, then Beckmann
+        std::vector<float4> t(2 * 2 * 4096, make_float4(0.f, 0.f, 0.f, 0.f));
+        const float* src[2] = {d->ltc_ggx, d->ltc_beckmann};
+        for (int w = 0; w < 2; w++)
+            for (int k = 0; src[w] && k < 4096; k++) {
+                t[(size_t)w * 8192 + 2 * k] = make_float4(src[w][5 * k], src[w][5 * k + 1], src[w][5 * k + 2], src[w][5 * k + 3]);
+                t[(size_t)w * 8192 + 2 * k + 1] = make_float4(src[w][5 * k + 4], 0.f, 0.f, 0.f);
+            }
+        if ((rc = s->ltc.upload(t))) return rc;
+    }
     ds.nodes = s->nodes.p;
     { const char* e = std::getenv("RGK_WALK_Q"); ds.walk_q = e ? (uint32_t)std::atoi(e) : 4u; }
     if (std::getenv("RGK_DEBUG_BVH")) std::fprintf(stderr, "[rgk] bvh4 nodes %zu max_stack %u max_depth %u\n", qb.out.size(), qb.max_stack, qb.max_depth);
     ds.tris = s->tris.p; ds.tri_shade = s->tri_shade.p;
     ds.materials = s->materials.p; ds.texels = s->texels.p; ds.texels8 = s->texels8.p; ds.luts = s->luts.p;
     ds.pointlights = s->pointlights.p; ds.areal = s->areal.p; ds.areal_tris = s->areal_tris.p;
-    ds.ltc_ggx = s->ltc_ggx.p; ds.ltc_beckmann = s->ltc_beckmann.p; ds.hdims = s->hdims.p; ds.hperm = s->hperm.p;
+    ds.ltc = s->ltc.p; ds.hdims = s->hdims.p; ds.hperm = s->hperm.p;
     ds.n_pointlights = (uint32_t)pls.size(); ds.n_areal = (uint32_t)als.size();
     ds.total_point_power = total_point; ds.total_areal_power = total_areal;
     ds.has_texcoords = d->texcoords ? 1u : 0u;
     ds.sky_mode = d->sky_mode;
     for (int k = 0; k < 3; k++) ds.sky_color[k] = d->sky_color[k];
     ds.sky_intensity = d->sky_intensity; ds.sky_rotate = d->sky_rotate; ds.sky_tex = tref(d->sky_mode == RGK_SKY_ENVMAP ? d->sky_texture : -1);
+    if ((rc = s->self.alloc(1))) return rc;
+    ds.self = s->self.p;
+    if (hipMemcpy(s->self.p, &ds, sizeof(DevScene), hipMemcpyHostToDevice) != hipSuccess) return fail(RGK_ERR_DEVICE, "hipMemcpy(DevScene)");
 
     rgk_scene_info& inf = s->info;
     inf.epsilon = eps;
@@ -770,7 +776,7 @@ static void make_camera(const rgk_camera* c, DevCamera& o) {
 // 2^27 2398, 2^28 2440 -- fewer, longer launches and shorter tails).  RGK_BATCH_PATHS overrides.
 static size_t batch_paths(uint32_t reverse) {
     if (const char* e = getenv("RGK_BATCH_PATHS")) return std::max<size_t>(1024, strtoull(e, nullptr, 10));
-    const size_t per_path = 176 + (reverse ? 48 + 64 * (size_t)reverse + 16 * ((size_t)reverse + 1) + 48 * (size_t)reverse : 0);
+    const size_t per_path = 180 + (reverse ? 48 + 64 * (size_t)reverse + 16 * ((size_t)reverse + 1) + 48 * (size_t)reverse : 0);
     const char* g = getenv("RGK_WORKSPACE_GB");
     const double gb = g ? atof(g) : 48.0;
     size_t b = (size_t)(gb * 1e9 / (double)per_path);
@@ -855,7 +861,7 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
     pp.pix_xy = s->pix_xy.p; pp.pix_seed = s->pix_seed.p;
     if ((rc = s->htab.alloc((size_t)192 * prm->multisample))) return rc;
     TIMED(3, rgk_launch_build_halton_table(st, s->dev, prm->multisample, s->htab.p));
-    pp.htab = s->htab.p; pp.light = s->light.p;
+    pp.htab = s->htab.p; pp.light = s->light.p; pp.generic = s->generic.p;
     for (size_t j0 = 0; j0 < P; j0 += npix_pass) {
         pp.j0 = (uint32_t)j0;
         pp.npix = (uint32_t)std::min(npix_pass, P - j0);

@@ -19,7 +19,8 @@
 #define RGK_CNT_SHADOW 64   // [b]  shadow rays issued at bounce b
 #define RGK_CNT_FETCH_T 128 // [b]  work-fetch cursor of k_trace_closest at bounce b
 #define RGK_CNT_FETCH_S 192 // [b]  work-fetch cursor of k_trace_shadow at bounce b
-#define RGK_CNT_TOTAL 256
+#define RGK_CNT_GENERIC 256 // [b]  vertices of bounce b left to the generic-BxDF shade launch
+#define RGK_CNT_TOTAL 320
 
 // what k_trace_shadow does with a visible ray's payload
 #define RGK_SHADOW_ADD 0   // tot[slot] += radiance                     (uni-directional path)
@@ -44,6 +45,7 @@ struct PassParams {
     float4* vfin;             // {contribution.rgb, 1 if the slot has a vertex awaiting k_finish_vertex}
     float4* vemit;            // emission of that vertex if front-facing
     uint32_t batch;
+    uint32_t* generic;        // queue indices of the vertices whose material takes the generic BxDF route (k_shade)
 };
 
 void rgk_launch_init_counters(hipStream_t st, uint32_t* counters, uint32_t n0);

@@ -63,22 +63,27 @@ __global__ __launch_bounds__(256) void k_raygen(const DevScene sc, const DevCame
 
 // ------------------------------------------------------------------ K3+K4+K6+K7: shade
 
+template <bool GENERIC>
 __global__ __launch_bounds__(RGK_SHADE_BLOCK, RGK_SHADE_WAVES) void k_shade(const DevScene sc, const DevCamera cam, const PassParams pp, const uint32_t bounce,
                                                             const float4* __restrict__ rayA, const float4* __restrict__ rayB,
                                                             const float4* __restrict__ hit, float4* __restrict__ thr, float4* __restrict__ tot,
                                                             float4* __restrict__ nextA, float4* __restrict__ nextB, float4* __restrict__ shA,
                                                             float4* __restrict__ shB, float4* __restrict__ shC, uint32_t* __restrict__ counters) {
-    const uint32_t count = counters[RGK_CNT_QUEUE + bounce];
+    // GENERIC = false: every vertex whose material takes the fast route (diffuse, LTC); the others (mirror, dielectric,
+    // transparent, mix) are only LISTED here and shaded by the GENERIC = true launch that follows, which walks that
+    // list with the full BxDF code.  Keeping the rare, big generic route out of this kernel takes its scratch from
+    // 136 to 24 bytes per thread -- and the kernel is bound by the bytes it moves.
+    const uint32_t count = counters[(GENERIC ? RGK_CNT_GENERIC : RGK_CNT_QUEUE) + bounce];
     const int lane = threadIdx.x & 63;
     const float eps = sc.epsilon;
     const SamplerTab tb = {pp.htab, pp.multisample};
-    __shared__ uint32_t s_cnt[2][RGK_SHADE_BLOCK / 64];
-    __shared__ uint32_t s_base[2];
+    __shared__ uint32_t s_cnt[3][RGK_SHADE_BLOCK / 64];
+    __shared__ uint32_t s_base[3];
     // workgroup-uniform trip count (the compaction below synchronises the workgroup)
     for (uint32_t base = blockIdx.x * RGK_SHADE_BLOCK; base < count; base += gridDim.x * RGK_SHADE_BLOCK) {
-        const uint32_t i = base + threadIdx.x;
-        const bool valid = i < count;
-        bool cont = false, shadow = false;
+        const bool valid = base + threadIdx.x < count;
+        const uint32_t i = !valid ? 0u : (GENERIC ? pp.generic[base + threadIdx.x] : base + threadIdx.x);
+        bool cont = false, shadow = false, defer = false;
         float4 nA = make_float4(0, 0, 0, 0), nB = nA, sA = nA, sB = nA, sC = nA;
         if (valid) {
             const float4 a = rayA[i], b = rayB[i], h = hit[i];
@@ -103,11 +108,13 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, RGK_SHADE_WAVES) void k_shade(cons
                 t.x = t.x + add.x; t.y = t.y + add.y; t.z = t.z + add.z;
                 tot[slot] = t;
             } else {
-                // one contiguous 112-byte record per triangle: {nA,uvA.x}{nB,uvA.y}{nC,uvB.x}{tA,uvB.y}{tB,uvC.x}{tC,uvC.y}{mat}
-                const float4* tsr = reinterpret_cast<const float4*>(sc.tri_shade) + 7 * (size_t)tri;
-                const float4 g0 = tsr[0], g1 = tsr[1], g2 = tsr[2];
-                const uint32_t mat_id = __float_as_uint(tsr[6].x);
-                const DevMaterial mat = sc.materials[mat_id];
+                // one 128-byte line per triangle: {nA,uvA.x}{nB,uvA.y}{nC,uvB.x}{tA,uvB.y}{tB,uvC.x}{tC,uvC.y}{mat}
+                const uint32_t tsr = (uint32_t)tri * (uint32_t)sizeof(TriShade);
+                const float4 g0 = gld_f4(sc.tri_shade, tsr), g1 = gld_f4(sc.tri_shade, tsr + 16u), g2 = gld_f4(sc.tri_shade, tsr + 32u);
+                const uint32_t mat_id = gld_u32(sc.tri_shade, tsr + 96u);
+                const DevMaterial mat = gld_rec<DevMaterial>(sc.materials, mat_id * (uint32_t)sizeof(DevMaterial));
+                defer = !GENERIC && !mat_is_fast(mat.kind);
+                if (!defer) {
                 const float al = h.y, be = h.z;
                 const float ia = 1.0f - al - be, ib = al, ic = be; // Intersection::a,b,c scene_intersect.cpp:280-283
                 f3 pos = o + h.x * d;
@@ -121,14 +128,15 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, RGK_SHADE_WAVES) void k_shade(cons
                 if (ok && len3(faceN) <= 0.0f) ok = false; // path_tracer.cpp:175
                 if (ok) {
                     faceN = norm3(faceN);
-                    const float4 g3 = tsr[3], g4 = tsr[4], g5 = tsr[5];
+                    const float4 g3 = gld_f4(sc.tri_shade, tsr + 48u), g4 = gld_f4(sc.tri_shade, tsr + 64u), g5 = gld_f4(sc.tri_shade, tsr + 80u);
                     float2 uv = make_float2(0.f, 0.f);
                     if (sc.has_texcoords) {
                         uv.x = ia * g0.w + ib * g2.w + ic * g4.w;
                         uv.y = ia * g1.w + ib * g3.w + ic * g5.w;
                     }
+                    const bool bumped = tex_kind(mat.t_bump) != RGK_TEXREF_NONE;
                     f3 lightN = faceN;
-                    if (mat.t_bump.kind != RGK_TEXREF_NONE) { // bump, path_tracer.cpp:204-231
+                    if (bumped) { // bump, path_tracer.cpp:204-231
                         float right, bottom;
                         tex_slopes(sc, mat.t_bump, uv, right, bottom);
                         f3 tangent = ia * mk3(g3.x, g3.y, g3.z) + ib * mk3(g4.x, g4.y, g4.z) + ic * mk3(g5.x, g5.y, g5.z);
@@ -158,7 +166,7 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, RGK_SHADE_WAVES) void k_shade(cons
                         const quatf l2g = qinverse(g2l);
                         float2 u = sample2d_t(tb, seed, s, base2d + 3u + (n - 1u));
                         f3 dirL, weight; bool may_leak;
-                        mat_sample(sc, (int)mat_id, mat, mp, VrL, uv, u, dirL, weight, may_leak);
+                        mat_sample<GENERIC>(sc, (int)mat_id, mat, mp, VrL, uv, u, dirL, weight, may_leak);
                         inside = dirL.z < 0;
                         dir = qrot(l2g, dirL);
                         if (!(dot3(dir, faceN) * dot3(Vr, faceN) > 0) && !may_leak) n_eff += 10000u; // leak, :252-260
@@ -186,7 +194,7 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, RGK_SHADE_WAVES) void k_shade(cons
                             const f3 sd = norm3(diff);
                             const float slen = len3(diff);
                             const f3 Vi = norm3(L.pos - pos);
-                            const f3 f = mat_value(sc, (int)mat_id, mat, mp, qrot(g2l, Vi), VrL, uv);
+                            const f3 f = mat_value<GENERIC>(sc, (int)mat_id, mat, mp, qrot(g2l, Vi), VrL, uv);
                             const float G = fabsf(dot3(lightN, Vi)) / dot3(diff, diff);
                             const float k = L.intensity * light_dir_factor(L, -Vi);
                             const f3 inc = L.color * mk3(k, k, k);
@@ -220,23 +228,30 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, RGK_SHADE_WAVES) void k_shade(cons
                         thr[slot] = make_float4(cum.x, cum.y, cum.z, __uint_as_float((n & 0xffffu) | (c1 << 16)));
                     }
                 }
+                } // !defer
             }
         }
-        // ---- K7: compaction into the next queues.  Wave ballot + prefix popcount inside the wave,
-        // the waves of the workgroup add up through LDS, and ONE atomic per workgroup and queue
-        // reserves the range (a single counter word only sustains ~88 returning atomics/us chip-wide).
+        // ---- K7: compaction into the next queues.
         {
-            const unsigned long long m = __ballot(cont), ms = __ballot(shadow);
+            // Wave ballot + prefix popcount inside the wave, the waves of the workgroup add up through LDS, and ONE
+            // atomic per workgroup and queue reserves the range.
+            const unsigned long long m = __ballot(cont), ms = __ballot(shadow), md = __ballot(defer);
             const int w = threadIdx.x >> 6;
-            if (lane == 0) { s_cnt[0][w] = __popcll(m); s_cnt[1][w] = __popcll(ms); }
+            if (lane == 0) { s_cnt[0][w] = __popcll(m); s_cnt[1][w] = __popcll(ms); s_cnt[2][w] = __popcll(md); }
             __syncthreads();
             if (threadIdx.x == 0) {
-                uint32_t t0 = 0, t1 = 0;
-                for (int k = 0; k < RGK_SHADE_BLOCK / 64; k++) { uint32_t a = s_cnt[0][k], b = s_cnt[1][k]; s_cnt[0][k] = t0; s_cnt[1][k] = t1; t0 += a; t1 += b; }
+                uint32_t t0 = 0, t1 = 0, t2 = 0;
+                for (int k = 0; k < RGK_SHADE_BLOCK / 64; k++) {
+                    uint32_t a = s_cnt[0][k], b = s_cnt[1][k], c = s_cnt[2][k];
+                    s_cnt[0][k] = t0; s_cnt[1][k] = t1; s_cnt[2][k] = t2;
+                    t0 += a; t1 += b; t2 += c;
+                }
                 s_base[0] = t0 ? atomicAdd(&counters[RGK_CNT_QUEUE + bounce + 1], t0) : 0u;
                 s_base[1] = t1 ? atomicAdd(&counters[RGK_CNT_SHADOW + bounce], t1) : 0u;
+                s_base[2] = t2 ? atomicAdd(&counters[RGK_CNT_GENERIC + bounce], t2) : 0u;
             }
             __syncthreads();
+            if (!GENERIC && defer) pp.generic[s_base[2] + s_cnt[2][w] + __popcll(md & ((1ull << lane) - 1ull))] = i;
             if (cont) {
                 uint32_t p = s_base[0] + s_cnt[0][w] + __popcll(m & ((1ull << lane) - 1ull));
                 nextA[p] = nA; nextB[p] = nB;
@@ -376,7 +391,9 @@ void rgk_launch_trace_shadow(hipStream_t st, const DevScene& sc, int stack, bool
 void rgk_launch_shade(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t bounce, const float4* rayA,
                       const float4* rayB, const float4* hit, float4* thr, float4* tot, float4* nextA, float4* nextB, float4* shA,
                       float4* shB, float4* shC, uint32_t* counters) {
-    k_shade<<<256 * 4 * (512 / RGK_SHADE_BLOCK), RGK_SHADE_BLOCK, 0, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
+    k_shade<false><<<256 * 4 * (512 / RGK_SHADE_BLOCK), RGK_SHADE_BLOCK, 0, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
+    // the vertices the first launch listed (materials on the generic BxDF route); returns at once when there are none
+    k_shade<true><<<256 * 2 * (512 / RGK_SHADE_BLOCK), RGK_SHADE_BLOCK, 0, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
 }
 
 void rgk_launch_resolve(hipStream_t st, const PassParams& pp, const float4* tot, float4* pixsum, float* accum_rgb, uint32_t* accum_count) {

@@ -174,6 +174,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
             if (COUNT) n_nodes++;
             const float limit = ANY ? thi : fminf(thi, best_t);
             // one 64-byte QNode: {p.xyz, sx} {child[4]} {qlo.x qlo.y qlo.z qhi.x} {qhi.y qhi.z sy sz}
+            // (the SGPR-base + 32-bit-offset load form of rgk_device.h gld_* was measured here: 23.8 vs 23.0 ms, not kept)
             const float4 n0 = nodes[4 * cur + 0], n1 = nodes[4 * cur + 1], n2 = nodes[4 * cur + 2], n3 = nodes[4 * cur + 3];
             const float sx = n0.w, sy = n3.z, sz = n3.w; // per-axis quantisation step (a power of two)
             // plane distance along the ray: t = (p + q*s - o) / d = q * (s/d) + (p - o)/d, one fma per plane.
