@@ -74,6 +74,65 @@ struct Box {
     }
 };
 
+// Early split clipping of large triangles (reference-splitting before the build): a triangle whose box is longer
+// than `lmax` on some axis enters the build as several references, one per piece of the triangle clipped at the
+// box midpoint, each with the tight box of its piece.  The pieces tile the triangle, so every hit point lies in
+// the (eps-padded) box of a reference; the leaf records are whole triangles, so a hit is what it was -- the tree
+// just stops dragging wall- and floor-sized boxes through its upper levels.
+struct RefSplitter {
+    struct P3 { double x[3]; };
+    float lmax;
+    size_t budget; // extra references still allowed
+    std::vector<Prim>* out;
+    static void clip(const std::vector<P3>& in, int ax, double plane, bool keep_below, std::vector<P3>& res) {
+        res.clear();
+        const size_t n = in.size();
+        for (size_t i = 0; i < n; i++) {
+            const P3 &a = in[i], &b = in[(i + 1) % n];
+            const bool ia = keep_below ? a.x[ax] <= plane : a.x[ax] >= plane, ib = keep_below ? b.x[ax] <= plane : b.x[ax] >= plane;
+            if (ia) res.push_back(a);
+            if (ia != ib) {
+                const double t = (plane - a.x[ax]) / (b.x[ax] - a.x[ax]);
+                P3 m;
+                for (int k = 0; k < 3; k++) m.x[k] = a.x[k] + t * (b.x[k] - a.x[k]);
+                m.x[ax] = plane;
+                res.push_back(m);
+            }
+        }
+    }
+    void emit(const std::vector<P3>& poly, const float* bmin, const float* bmax, uint32_t tri, int depth) {
+        // tight box of the piece: polygon bounds (outward-rounded to float) within the parent's box
+        Prim p;
+        for (int a = 0; a < 3; a++) {
+            double lo = std::numeric_limits<double>::infinity(), hi = -lo;
+            for (const P3& v : poly) { lo = std::min(lo, v.x[a]); hi = std::max(hi, v.x[a]); }
+            float fl = (float)lo, fh = (float)hi;
+            if ((double)fl > lo) fl = std::nextafterf(fl, -std::numeric_limits<float>::infinity());
+            if ((double)fh < hi) fh = std::nextafterf(fh, std::numeric_limits<float>::infinity());
+            p.bmin[a] = std::max(fl, bmin[a]); p.bmax[a] = std::min(fh, bmax[a]);
+            if (p.bmin[a] > p.bmax[a]) p.bmin[a] = p.bmax[a] = 0.5f * (bmin[a] + bmax[a]);
+        }
+        int ax = 0;
+        for (int a = 1; a < 3; a++) if (p.bmax[a] - p.bmin[a] > p.bmax[ax] - p.bmin[ax]) ax = a;
+        if (!(p.bmax[ax] - p.bmin[ax] > lmax) || depth >= 12 || budget == 0 || poly.size() < 3) {
+            for (int a = 0; a < 3; a++) p.c[a] = 0.5f * (p.bmin[a] + p.bmax[a]);
+            p.tri = tri;
+            out->push_back(p);
+            return;
+        }
+        budget--;
+        const double mid = 0.5 * ((double)p.bmin[ax] + (double)p.bmax[ax]);
+        std::vector<P3> lo, hi;
+        clip(poly, ax, mid, true, lo);
+        clip(poly, ax, mid, false, hi);
+        float cmax[3] = {p.bmax[0], p.bmax[1], p.bmax[2]}, cmin[3] = {p.bmin[0], p.bmin[1], p.bmin[2]};
+        cmax[ax] = std::nextafterf((float)mid, std::numeric_limits<float>::infinity());
+        cmin[ax] = std::nextafterf((float)mid, -std::numeric_limits<float>::infinity());
+        if (lo.size() >= 3) emit(lo, p.bmin, cmax, tri, depth + 1);
+        if (hi.size() >= 3) emit(hi, cmin, p.bmax, tri, depth + 1);
+    }
+};
+
 struct BvhBuilder {
     std::vector<Prim>& prims;
     std::vector<BvhNode> nodes;
@@ -497,6 +556,14 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
     std::vector<TriIsect> recs(nt);
     std::vector<Prim> prims;
     prims.reserve(nt);
+    RefSplitter splitter;
+    {   // RGK_BVH_SPLIT = longest box side, as a fraction of the scene diagonal, above which a triangle is pre-split
+        const char* e = std::getenv("RGK_BVH_SPLIT");
+        const float f = e ? (float)std::atof(e) : 0.1f; // swept on the Sponza proxy: 0.08..0.15 best (-7 % node visits); finer splits deepen the tree
+        splitter.lmax = f > 0.f ? f * (eps * 1e5f) : 0.f; // eps = 1e-5 * diagonal
+        splitter.budget = (size_t)nt; // at most 2x references
+        splitter.out = &prims;
+    }
     for (uint32_t i = 0; i < nt; i++) {
         V3 v0 = vert(d->tri_indices[3 * i]), v1 = vert(d->tri_indices[3 * i + 1]), v2 = vert(d->tri_indices[3 * i + 2]);
         V3 d0 = sub(v1, v0), d1 = sub(v2, v0);
@@ -522,7 +589,12 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
                 p.c[a] = 0.5f * (p.bmin[a] + p.bmax[a]);
             }
             p.tri = i;
-            prims.push_back(p);
+            if (splitter.lmax > 0.f) {
+                std::vector<RefSplitter::P3> poly(3);
+                for (int a = 0; a < 3; a++) { poly[0].x[a] = comp(v0, a); poly[1].x[a] = comp(v1, a); poly[2].x[a] = comp(v2, a); }
+                splitter.emit(poly, p.bmin, p.bmax, i, 0);
+            } else
+                prims.push_back(p);
         }
     }
     // ---- accelerator
@@ -559,7 +631,7 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
     qb.out.reserve(nodes.size() / 2 + 1);
     if (qb.collapse(0, 0, 0) != 0) return fail(RGK_ERR_DEVICE, "internal: QBVH root is not node 0");
     if (qb.max_stack + 1 > 64) return fail(RGK_ERR_UNSUPPORTED, "BVH needs %u traversal-stack entries (max 64)", qb.max_stack + 1);
-    s->stack = (qb.max_stack + 1 <= 32) ? 32 : 64;
+    s->stack = (qb.max_stack + 1 <= 32) ? 32 : ((qb.max_stack + 1 <= 48) ? 48 : 64);
     max_depth = qb.max_depth;
 
     // ---- shading arrays
@@ -695,7 +767,7 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
     }
     ds.nodes = s->nodes.p;
     { const char* e = std::getenv("RGK_WALK_Q"); ds.walk_q = e ? (uint32_t)std::atoi(e) : 4u; }
-    if (std::getenv("RGK_DEBUG_BVH")) std::fprintf(stderr, "[rgk] bvh4 nodes %zu max_stack %u max_depth %u\n", qb.out.size(), qb.max_stack, qb.max_depth);
+    if (std::getenv("RGK_DEBUG_BVH")) std::fprintf(stderr, "[rgk] bvh4 nodes %zu max_stack %u max_depth %u refs %zu of %u triangles\n", qb.out.size(), qb.max_stack, qb.max_depth, leaf_recs.size(), nt);
     ds.tris = s->tris.p; ds.tri_shade = s->tri_shade.p;
     ds.materials = s->materials.p; ds.texels = s->texels.p; ds.texels8 = s->texels8.p; ds.luts = s->luts.p;
     ds.pointlights = s->pointlights.p; ds.areal = s->areal.p; ds.areal_tris = s->areal_tris.p;

@@ -347,6 +347,7 @@ __global__ void k_sampler_eval(const DevScene sc, uint32_t n, const uint32_t* se
 }
 
 // ------------------------------------------------------------------ launch wrappers (host)
+#define RGK_STACK_MID (RGK_TRACE_BLOCK <= 256 ? 48 : 32)
 #define RGK_STACK_BIG (RGK_TRACE_BLOCK <= 256 ? 64 : 32) // tuning variants with larger workgroups only serve 32-entry stacks
 static inline int trace_grid(int stack) {
     // LDS-limited residency: STACK*256*4 B per block out of 160 KiB, 256 CUs
@@ -374,6 +375,7 @@ void rgk_launch_trace_closest(hipStream_t st, const DevScene& sc, int stack, boo
     int grid = trace_grid(stack);
 #define L(C, S) { k_trace_closest<C, S><<<grid, RGK_TRACE_BLOCK, 0, st>>>(sc, rayA, rayB, nearfar, hit, count_ptr, fetch, stats); }
     if (stack <= 32) { if (count_stats) L(true, 32) else L(false, 32) }
+    else if (stack <= 48 && RGK_TRACE_BLOCK <= 256) { if (count_stats) L(true, RGK_STACK_MID) else L(false, RGK_STACK_MID) }
     else { if (count_stats) L(true, RGK_STACK_BIG) else L(false, RGK_STACK_BIG) }
 #undef L
 }
@@ -384,6 +386,7 @@ void rgk_launch_trace_shadow(hipStream_t st, const DevScene& sc, int stack, bool
     int grid = trace_grid(stack);
 #define L(C, S) { k_trace_shadow<C, S><<<grid, RGK_TRACE_BLOCK, 0, st>>>(sc, shA, shB, shC, tot, vis_out, mode, splat_rgb, count_ptr, fetch, stats); }
     if (stack <= 32) { if (count_stats) L(true, 32) else L(false, 32) }
+    else if (stack <= 48 && RGK_TRACE_BLOCK <= 256) { if (count_stats) L(true, RGK_STACK_MID) else L(false, RGK_STACK_MID) }
     else { if (count_stats) L(true, RGK_STACK_BIG) else L(false, RGK_STACK_BIG) }
 #undef L
 }

@@ -1,11 +1,12 @@
 # usage: tools/env_sweep.sh "VAR=a" "VAR=b OTHER=c" ...  -- bench the product library under each environment
 for e in "$@"; do
   tag=$(echo "$e" | tr ' =/' '___')
-  env $e timeout -k 10 200 python bench.py --no-cpu-baseline --steps 2 > gpurun_out/env_$tag.json 2> gpurun_out/env_$tag.err || { echo "$e failed"; tail -3 gpurun_out/env_$tag.err; exit 1; }
+  env RGK_DEBUG_BVH=1 $e timeout -k 10 200 python bench.py --no-cpu-baseline --steps 2 > gpurun_out/env_$tag.json 2> gpurun_out/env_$tag.err || { echo "$e failed"; tail -3 gpurun_out/env_$tag.err; exit 1; }
   python - <<PY
 import json
 d=json.load(open("gpurun_out/env_$tag.json"))
 r=d["roofline"]
-print("$e", d["value"], "trace_ms", r["avg_launch_ms"], r["other_kernels_ms"])
+print("$e", d["value"], "trace_ms", r["avg_launch_ms"], "nodes", r["nodes_per_ray"], "tris", r["tris_per_ray"], r["other_kernels_ms"])
 PY
+  grep "rgk\] bvh4" gpurun_out/env_$tag.err | head -1
 done
