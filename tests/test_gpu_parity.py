@@ -244,6 +244,33 @@ def test_dragon_sponza_config4_small(rd, oracle):
     assert abs(int(kg.path_rays) - int(ko.path_rays)) <= 2e-3 * ko.path_rays
 
 
+def test_envmap_sky_float_texture(rd, oracle):
+    """Scene::GetSkyboxRay in envmap mode (scene.cpp:748-763): lat-long lookup with rotation into a float (HDR-style)
+    texture -- the kind BASELINE configs[3] names but the reference checkout does not ship."""
+    rng = np.random.default_rng(11)
+    sb = SceneBuilder()
+    m = sb.new_material("grey", capi.BXDF_LTC_GGX_DIFFUSE)
+    m["tex_diffuse"] = sb.create_solid_texture((0.5, 0.5, 0.5)); m["tex_color"] = sb.create_solid_texture((0.3, 0.3, 0.3)); m["roughness"] = 0.4
+    sb.register_material(m)
+    from rgk_amd.scene import glm_mat4_mul, glm_scale, glm_translate
+    sb.add_primitive("plane", glm_scale((4, 1, 4)), "grey")
+    sb.add_primitive("cube", glm_mat4_mul(glm_translate((0, 0.5, 0)), glm_scale((0.5, 0.5, 0.5))), "grey")
+    hdr = (rng.random((64, 128, 3)) ** 4 * 6).astype(np.float32)           # a few bright spots
+    hdr[20:24, 30:36] = (40.0, 35.0, 30.0)
+    tex = sb.add_image_texture("sky", hdr)
+    sb.sky.update(mode=capi.SKY_ENVMAP, tex=tex, intensity=0.9, rotate=37.0)
+    W, H = 160, 120
+    cam = make_camera((2.5, 1.8, 3.0), (0, 0.4, 0), (0, 1, 0), fov=50, xres=W, yres=H)
+    prm = make_params(W, H, 16, 4, clamp=50.0, russian=0.8)
+    desc = sb.to_desc()
+    g, o = rd.Scene(desc), oracle.OracleScene(desc)
+    ag, cg, _ = g.render_round(cam, prm, rd.generate_task_list(W, H))
+    ao, co, _ = o.render_round(cam, prm, oracle.generate_task_list(W, H))
+    img, ref = ag / cg[..., None], ao / co[..., None]
+    rel, within = image_metrics(img, ref, 50.0, 16)
+    assert ref.max() > 1.0 and rel <= 2e-3, (rel, within)   # libm atan2f / asinf differences only
+
+
 def material_zoo():
     """Cornell-like box exercising mirror, dielectric, transparent, mix, ltc_beckmann, no-russian, thin lens."""
     sb = SceneBuilder()
