@@ -253,6 +253,24 @@ int rgk_trace_visibility(rgk_scene *scene, uint32_t n, const float *a, const flo
 int rgk_sampler_eval(uint32_t n, const uint32_t *seed, const uint32_t *index,
                      const uint32_t *dim, int is2d, float *out);
 
+/* ---- output path: what RenderFrame does with total_ob after each round ---------------------- */
+
+/* EXRTexture::Normalize followed by the GetPixel that Write applies (src/texture.cpp:349-354,376-400,
+ * src/render_driver.cpp:233,245): out_rgb[p] = (accum_rgb[p] * val) / accum_count[p], 0 where the count is 0.
+ * output_scale <= 0 ("auto", the reference's default, config.cpp:303-311): val = 1 / (largest channel of
+ * accum/count), so the brightest channel becomes 1.  Host buffers; *scale_used receives val (may be NULL). */
+int rgk_output_normalize(const float *accum_rgb, const uint32_t *accum_count, uint32_t xres, uint32_t yres,
+                         float output_scale, float *out_rgb, float *scale_used);
+
+/* EXRTexture::Write (src/texture.cpp:356-374): a scan-line OpenEXR file of half-float R, G, B from rgb
+ * (xres * yres * 3 floats, row-major from the top row) and A = 1.  float -> half is OpenEXR's conversion (round
+ * to nearest even, overflow to infinity).  Written uncompressed; the reference's RgbaOutputFile default is PIZ --
+ * the same pixels in another container encoding. */
+int rgk_output_write_exr(const char *path, uint32_t xres, uint32_t yres, const float *rgb);
+
+/* float -> IEEE half bits exactly as the writer stores them (exposed for the tests). */
+uint16_t rgk_float_to_half(float v);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "librgk_hip.so")
-SOURCES = ["rgk_kernels.hip", "rgk_host.cpp"]
+SOURCES = ["rgk_kernels.hip", "rgk_host.cpp", "rgk_output.cpp"]
 HEADERS = ["rgk_kernels.h", "rgk_device.h", "rgk_trace.h", "rgk_bdpt.h", "device_types.h", os.path.join("..", "..", "include", "rgk.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          # CPU/GPU agreement: no FMA contraction on either side (DESIGN.md "Numerics")

@@ -108,7 +108,7 @@ class Hit(C.Structure):
 EXPORTS = ["rgk_last_error", "rgk_device_count", "rgk_scene_create", "rgk_scene_destroy",
            "rgk_scene_get_info", "rgk_generate_task_list", "rgk_render_round",
            "rgk_render_round_device", "rgk_trace_closest", "rgk_trace_visibility",
-           "rgk_sampler_eval"]
+           "rgk_sampler_eval", "rgk_output_normalize", "rgk_output_write_exr", "rgk_float_to_half"]
 
 _p = C.POINTER
 
@@ -131,6 +131,10 @@ def _bind(lib):
                                          C.c_void_p, _p(Counters)]
     lib.rgk_sampler_eval.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                      C.c_void_p]
+    lib.rgk_output_normalize.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p, _p(C.c_float)]
+    lib.rgk_output_write_exr.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    lib.rgk_float_to_half.argtypes = [C.c_float]
+    lib.rgk_float_to_half.restype = C.c_uint16
     return lib
 
 

@@ -342,6 +342,8 @@ struct DevBuf {
 
 } // namespace
 
+extern "C" __attribute__((visibility("hidden"))) int rgk_internal_fail(int code, const char* msg) { return fail(code, "%s", msg); }
+
 struct rgk_scene {
     int device = 0;
     hipStream_t stream = nullptr;

@@ -114,6 +114,35 @@ def sampler_eval(seed, index, dim, is2d):
     return out
 
 
+def read_exr(path):
+    """Minimal reader for the files rgk_output_write_exr writes (uncompressed scan-line half RGBA): (h, w, 4) float32
+    in R, G, B, A order.  Test infrastructure for the round trip, not a general OpenEXR reader."""
+    import struct
+    b = open(path, "rb").read()
+    assert struct.unpack_from("<ii", b, 0) == (20000630, 2)
+    pos, attrs = 8, {}
+    while b[pos] != 0:
+        e = b.index(b"\0", pos); name = b[pos:e].decode(); pos = e + 1
+        e = b.index(b"\0", pos); typ = b[pos:e].decode(); pos = e + 1
+        (size,) = struct.unpack_from("<i", b, pos); pos += 4
+        attrs[name] = (typ, b[pos:pos + size]); pos += size
+    pos += 1
+    x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"][1])
+    w, h = x1 - x0 + 1, y1 - y0 + 1
+    assert attrs["compression"][1] == b"\0"
+    chans, cp, cl = [], 0, attrs["channels"][1]
+    while cl[cp] != 0:
+        e = cl.index(b"\0", cp); chans.append(cl[cp:e].decode()); cp = e + 1 + 16
+    offs = struct.unpack_from("<%dQ" % h, b, pos)
+    img = np.zeros((h, w, 4), np.float32)
+    for y in range(h):
+        yy, n = struct.unpack_from("<ii", b, offs[y])
+        line = np.frombuffer(b, dtype=np.float16, count=w * len(chans), offset=offs[y] + 8).reshape(len(chans), w)
+        for k, c in enumerate(chans):
+            img[yy - y0, :, "RGBA".index(c)] = line[k]
+    return img
+
+
 class EXRTexture:
     """The Radiance accumulator (reference src/texture.hpp:83-118); device-resident torch tensors."""
 
@@ -135,6 +164,19 @@ class EXRTexture:
         if val <= 0.0:
             val = 1.0 / float(px.max())
         return px * val
+
+    def write(self, path, output_scale=-1.0):
+        """total_ob.Normalize(cfg->output_scale).Write(output_file) (render_driver.cpp:233,245) through the C ABI:
+        rgk_output_normalize + rgk_output_write_exr on host copies of the accumulator.  Returns the scale used."""
+        lib = capi.load_product()
+        acc = np.ascontiguousarray(self.data.cpu().numpy(), dtype=np.float32)
+        cnt = np.ascontiguousarray(self.count.cpu().numpy()).view(np.uint32)
+        out = np.empty_like(acc)
+        val = C.c_float(0.0)
+        capi.check(lib, lib.rgk_output_normalize(acc.ctypes.data, cnt.ctypes.data, self.xsize, self.ysize, float(output_scale),
+                                                 out.ctypes.data, C.byref(val)))
+        capi.check(lib, lib.rgk_output_write_exr(str(path).encode(), self.xsize, self.ysize, out.ctypes.data))
+        return val.value
 
 
 class RenderDriver:
@@ -187,15 +229,21 @@ class RenderDriver:
         self.counters.append(cnt)
         return cnt
 
-    def render_frame(self, rounds=None, minutes=None):
-        """RenderFrame: Rounds mode (render_driver.cpp:229-235) or Timed mode (:237-247)."""
+    def render_frame(self, rounds=None, minutes=None, output_file=None):
+        """RenderFrame: Rounds mode (render_driver.cpp:229-235) or Timed mode (:237-247); with `output_file` the
+        normalised image is rewritten after every round, as the reference does (rank 0 only)."""
         rounds = self.cfg.render_rounds if rounds is None else rounds
         minutes = self.cfg.render_minutes if minutes is None else minutes
         t0 = time.time()
+
+        def one():
+            self.render_round()
+            if output_file and self.rank == 0:
+                self.total_ob.write(output_file, getattr(self.cfg, "output_scale", -1.0))
         if minutes is None:
             for _ in range(rounds):
-                self.render_round()
+                one()
         else:
             while (time.time() - t0) / 60.0 < minutes:
-                self.render_round()
+                one()
         return self.total_ob

@@ -458,8 +458,9 @@ def test_device_accumulator_entry_point(rd, oracle, cornell):
     assert np.array_equal(acc.cpu().numpy(), ah) and np.array_equal(cnt.cpu().numpy().view(np.uint32), ch)
 
 
-def test_render_driver_rounds(rd, oracle, cornell):
-    """RenderFrame in rounds mode: seedcount advances across rounds like render_driver.cpp:160,222."""
+def test_render_driver_rounds(rd, oracle, cornell, tmp_path):
+    """RenderFrame in rounds mode: seedcount advances across rounds like render_driver.cpp:160,222; the image file is
+    rewritten after every round (:233) as Normalize(output_scale).Write."""
     import torch
     g, o = both(rd, oracle, cornell)
 
@@ -467,7 +468,7 @@ def test_render_driver_rounds(rd, oracle, cornell):
         xres, yres, render_rounds, render_minutes = cornell.xres, cornell.yres, 2, None
         get_params = staticmethod(lambda sampler=0, flags=0: cornell.params(sampler, flags))
     drv = rd.RenderDriver(g, Cfg, cornell.camera)
-    ob = drv.render_frame()
+    ob = drv.render_frame(output_file=str(tmp_path / "cornell.exr"))
     n = len(oracle.generate_task_list(cornell.xres, cornell.yres))
     acc = np.zeros((cornell.yres, cornell.xres, 3), np.float32); cnt = np.zeros((cornell.yres, cornell.xres), np.uint32)
     for r in range(2):
@@ -478,3 +479,6 @@ def test_render_driver_rounds(rd, oracle, cornell):
     px = ob.get_pixels().cpu().numpy()
     assert np.allclose(px, got / cnt[..., None], rtol=1e-6, atol=1e-7)
     assert float(ob.normalize(-1.0).max()) == pytest.approx(1.0)
+    img = rd.read_exr(str(tmp_path / "cornell.exr"))       # auto-normalised half-float RGBA, A = 1
+    assert img.shape == (cornell.yres, cornell.xres, 4) and (img[..., 3] == 1.0).all() and img[..., :3].max() == 1.0
+    assert np.allclose(img[..., :3], ob.normalize(-1.0).cpu().numpy(), rtol=2e-3, atol=1e-4)

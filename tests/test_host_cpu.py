@@ -222,3 +222,46 @@ def test_tile_sharding_and_reduce_world_size_2(oracle):
         osc.render_round(wl.camera, wl.params(), oracle.generate_task_list(wl.xres, wl.yres, seedcount_base=r * n), acc, cnt)
     assert np.array_equal(count.view(np.uint32), cnt)
     assert np.array_equal(data, acc)      # disjoint tiles: the reduce is exact, the image does not depend on G
+
+
+# ----------------------------------------------------------------------- output path
+def test_float_to_half_is_round_to_nearest_even(product_lib):
+    rng = np.random.default_rng(5)
+    bits = np.concatenate([rng.integers(0, 2 ** 32, 200000, dtype=np.uint64).astype(np.uint32),
+                           np.array([0, 0x80000000, 0x33000000, 0x33000001, 0x387fc000, 0x38800000, 0x477fefff, 0x477ff000,
+                                     0x7f800000, 0xff800000, 0x3f800000, 0x3f801000, 0x3f803000], dtype=np.uint32)])
+    vals = bits.view(np.float32)
+    vals = vals[np.isfinite(vals)]
+    with np.errstate(over="ignore"):
+        want = vals.astype(np.float16).view(np.uint16)   # IEEE round-to-nearest-even, what OpenEXR's half(float) yields
+    got = np.array([product_lib.rgk_float_to_half(float(v)) for v in vals[:20000]] , dtype=np.uint16)
+    assert np.array_equal(got, want[:20000])
+    tail = np.array([product_lib.rgk_float_to_half(float(v)) for v in vals[-13:]], dtype=np.uint16)
+    assert np.array_equal(tail, want[-13:])
+
+
+def test_output_normalize_and_exr_round_trip(product_lib, tmp_path):
+    """EXRTexture::Normalize + Write semantics (texture.cpp:349-400): auto scale = 1 / brightest channel of data/count,
+    pixel = (data * scale) / count, zero where count is 0; the file holds those values as halves with A = 1."""
+    import ctypes as C
+    from rgk_amd.render_driver import read_exr
+    rng = np.random.default_rng(6)
+    W, H = 37, 23
+    cnt = rng.integers(0, 5, (H, W)).astype(np.uint32) * 16
+    acc = np.ascontiguousarray((rng.random((H, W, 3)) * 40.0 * cnt[..., None]).astype(np.float32))
+    out = np.empty_like(acc)
+    val = C.c_float()
+    assert product_lib.rgk_output_normalize(acc.ctypes.data, cnt.ctypes.data, W, H, -1.0, out.ctypes.data, C.byref(val)) == 0
+    with np.errstate(invalid="ignore", divide="ignore"):
+        px = np.where(cnt[..., None] > 0, acc / cnt[..., None].astype(np.float32), 0).astype(np.float32)
+    assert val.value == np.float32(1.0) / px.max()
+    want = np.where(cnt[..., None] > 0, (acc * np.float32(val.value)) / np.maximum(cnt, 1)[..., None].astype(np.float32), 0).astype(np.float32)
+    assert np.array_equal(out, want) and out.max() <= 1.0 + 1e-6
+    assert product_lib.rgk_output_normalize(acc.ctypes.data, cnt.ctypes.data, W, H, 0.25, out.ctypes.data, None) == 0
+    assert np.array_equal(out, np.where(cnt[..., None] > 0, (acc * np.float32(0.25)) / np.maximum(cnt, 1)[..., None].astype(np.float32), 0).astype(np.float32))
+    path = str(tmp_path / "img.exr")
+    assert product_lib.rgk_output_write_exr(path.encode(), W, H, out.ctypes.data) == 0
+    img = read_exr(path)
+    assert img.shape == (H, W, 4) and (img[..., 3] == 1.0).all()
+    assert np.array_equal(img[..., :3], out.astype(np.float16).astype(np.float32))
+    assert product_lib.rgk_output_write_exr(b"/nonexistent-dir/x.exr", W, H, out.ctypes.data) != 0
