@@ -10,7 +10,7 @@
 // Execution model: persistent waves with per-lane ray REFILL.  Round-1 counters showed the
 // kernel is VALU-issue bound (SQ_ACTIVE_INST_ANY ~= all SIMD cycles) at ~1/3 lane utilisation:
 // rays of one 64-ray batch finish at very different times.  So a wave keeps a cursor into its
-// chunk of the ray queue and, whenever a quarter of its lanes are idle, hands them fresh rays
+// chunk of the ray queue and, whenever at most RGK_REFILL_BELOW of its lanes still hold a ray, hands the idle ones fresh rays
 // (ballot + prefix popcount); a lane that drains its stack stores its hit and goes idle.
 // The per-lane traversal stack lives in LDS as [entry][lane] (bank = lane: conflict-free).
 //
@@ -25,7 +25,9 @@
 #include "rgk_kernels.h"
 
 #define STACK_SENTINEL 0x7fffffff
-#define RGK_REFILL_BELOW 48 // refill a wave when at most this many lanes still hold a ray
+#ifndef RGK_REFILL_BELOW
+#define RGK_REFILL_BELOW 24 // refill a wave when at most this many lanes still hold a ray (swept 8..60 with the majority walk: 24 best)
+#endif
 
 // Triangle::TestIntersection, reference src/primitives.cpp:75-166.  r0..r2 = TriIsect.
 __device__ __forceinline__ bool tri_test(const float4 r0, const float4 r1, const float4 r2, const f3 o, const f3 d,
