@@ -140,6 +140,7 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade_light(const DevSce
     const SamplerTab tb = {pp.htab, pp.multisample};
     __shared__ uint32_t s_cnt[RGK_SHADE_BLOCK / 64];
     __shared__ uint32_t s_base;
+    lut_lds_fill(sc);
     for (uint32_t base = blockIdx.x * RGK_SHADE_BLOCK; base < count; base += gridDim.x * RGK_SHADE_BLOCK) {
         const uint32_t i = base + threadIdx.x;
         bool cont = false, splat = false;
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade_bdpt(const DevScen
     const SamplerTab tb = {pp.htab, pp.multisample};
     __shared__ uint32_t s_cnt[RGK_SHADE_BLOCK / 64];
     __shared__ uint32_t s_base;
+    lut_lds_fill(sc);
     for (uint32_t base = blockIdx.x * RGK_SHADE_BLOCK; base < count; base += gridDim.x * RGK_SHADE_BLOCK) {
         const uint32_t i = base + threadIdx.x;
         bool cont = false, have = false;

@@ -228,9 +228,22 @@ __device__ __forceinline__ uint32_t tex_row(const TexRef t, int y) { return (uin
 __device__ __forceinline__ uint32_t tex_col(const TexRef t, int x) { return (uint32_t)x; }
 // (Texels in 8 x 4 tiles of one 128-byte line each, so that a bilinear footprint mostly touches one line, were
 // measured: no change in the shade kernel's time, 134.5 vs 135.8 ms.  Row-major, like the reference.)
+// The first byte->float texel tables of the scene are copied into dynamic LDS by every kernel that shades
+// (lut_lds_fill at kernel entry; launch with RGK_LDS_LUT_FLOATS * 4 bytes of dynamic LDS): the three dependent
+// table loads per texel were 7 % of the shade kernel.
+#define RGK_LDS_LUT_FLOATS 512u
+extern __shared__ float rgk_lut_lds[];
+__device__ __forceinline__ void lut_lds_fill(const DevScene& sc) {
+    for (uint32_t k = threadIdx.x; k < RGK_LDS_LUT_FLOATS; k += blockDim.x) rgk_lut_lds[k] = k < sc.n_lut_floats ? gld_f32(sc.luts, k << 2) : 0.f;
+    __syncthreads();
+}
 __device__ __forceinline__ f3 texel_at(const DevScene& sc, const TexRef t, uint32_t idx) { // idx = tex_row + tex_col
     if (tex_kind(t) == RGK_TEX_RGB8) { // the bytes the 8-bit loaders keep + the table that makes them the reference's floats
         const uint32_t w = gld_u32(sc.texels8, (t.b + idx) << 2);
+        if (t.c + 256u <= RGK_LDS_LUT_FLOATS) { // the table sits in the workgroup's LDS (lut_lds_fill): 3 ds_read instead of 3 global loads
+            const float* lut = rgk_lut_lds + t.c;
+            return mk3(lut[w & 0xffu], lut[(w >> 8) & 0xffu], lut[(w >> 16) & 0xffu]);
+        }
         const uint32_t lut = t.c << 2;
         return mk3(gld_f32(sc.luts, lut + ((w & 0xffu) << 2)), gld_f32(sc.luts, lut + ((w >> 6) & 0x3fcu)), gld_f32(sc.luts, lut + ((w >> 14) & 0x3fcu)));
     }
@@ -242,6 +255,9 @@ __device__ __forceinline__ f3 texel_at(const DevScene& sc, const TexRef t, uint3
 __device__ __forceinline__ f3 tex_get(const DevScene& sc, const TexRef t, float2 uv) {
     if (tex_kind(t) == RGK_TEXREF_NONE) return mk3(0.f, 0.f, 0.f);
     if (tex_kind(t) == RGK_TEX_SOLID) return mk3(__uint_as_float(t.a), __uint_as_float(t.b), __uint_as_float(t.c));
+#ifdef RGK_EXP_NOTEX
+    return mk3(0.5f + uv.x * 1e-3f, 0.5f, 0.5f);
+#endif
     const int xsize = (int)(t.a & 0xffffu), ysize = (int)(t.a >> 16);
     float x = glm_repeat(uv.x) * xsize - 0.5f;
     float y = glm_repeat(uv.y) * ysize - 0.5f;
@@ -265,6 +281,9 @@ __device__ __forceinline__ f3 tex_get(const DevScene& sc, const TexRef t, float2
 __device__ __forceinline__ void tex_slopes(const DevScene& sc, const TexRef t, float2 uv, float& right, float& bottom) {
     right = 0.f; bottom = 0.f;
     if (tex_kind(t) != RGK_TEX_RGB32F && tex_kind(t) != RGK_TEX_RGB8) return;
+#if defined(RGK_EXP_NOTEX) || defined(RGK_EXP_NOBUMP)
+    right = uv.x * 1e-3f; bottom = uv.y * 1e-3f; return;
+#endif
     const int xsize = (int)(t.a & 0xffffu), ysize = (int)(t.a >> 16);
     int x = (int)(glm_repeat(uv.x) * xsize - 0.5f);
     int y = (int)(glm_repeat(uv.y) * ysize - 0.5f);
@@ -296,6 +315,9 @@ __device__ __forceinline__ LtcM ltc_bilinear(const void* ltc, uint32_t tab, floa
     const int s = 63;
     int t1 = (int)floorf(t * s), t2 = t1 + 1;
     int a1 = (int)floorf(a * s), a2 = a1 + 1;
+#ifdef RGK_EXP_NOLTC
+    { LtcM r; r.m0 = 1.f + t * 0.1f; r.m2 = 0.1f * a; r.m4 = 1.f; r.m6 = -0.1f; r.m8 = 1.f; r.amp = 0.9f; return r; }
+#endif
     const uint32_t o11 = tab + ((uint32_t)(a1 + t1 * 64) << 5), o12 = tab + ((uint32_t)(a2 + t1 * 64) << 5);
     const uint32_t o21 = tab + ((uint32_t)(a1 + t2 * 64) << 5), o22 = tab + ((uint32_t)(a2 + t2 * 64) << 5);
     const float4 m11 = gld_f4(ltc, o11), m12 = gld_f4(ltc, o12), m21 = gld_f4(ltc, o21), m22 = gld_f4(ltc, o22);
