@@ -349,7 +349,8 @@ struct rgk_scene {
     hipStream_t stream = nullptr;
     rgk_scene_info info{};
     DevScene dev{};
-    int stack = 32;
+    RgkTraceCfg tcfg{32, 32, nullptr};
+    DevBuf<int> ovf; // traversal-stack overflow area (deep trees)
     // scene data
     DevBuf<QNode> nodes;
     DevBuf<TriIsect> tris;
@@ -384,7 +385,7 @@ struct rgk_scene {
         for (auto e : events) (void)hipEventDestroy(e);
         if (h_counters) (void)hipHostFree(h_counters);
         nodes.release(); tris.release(); tri_shade.release(); materials.release(); texels8.release(); luts.release();
-        texels.release(); pointlights.release(); areal.release(); areal_tris.release(); ltc.release(); self.release();
+        texels.release(); pointlights.release(); areal.release(); areal_tris.release(); ltc.release(); self.release(); ovf.release();
         hdims.release(); hperm.release();
         for (int i = 0; i < 2; i++) { rayA[i].release(); rayB[i].release(); }
         hit.release(); thr.release(); tot.release(); shA.release(); shB.release(); shC.release(); pixsum.release();
@@ -632,8 +633,19 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
     QbvhBuilder qb(nodes);
     qb.out.reserve(nodes.size() / 2 + 1);
     if (qb.collapse(0, 0, 0) != 0) return fail(RGK_ERR_DEVICE, "internal: QBVH root is not node 0");
-    if (qb.max_stack + 1 > 64) return fail(RGK_ERR_UNSUPPORTED, "BVH needs %u traversal-stack entries (max 64)", qb.max_stack + 1);
-    s->stack = (qb.max_stack + 1 <= 32) ? 32 : ((qb.max_stack + 1 <= 48) ? 48 : 64);
+    if (qb.max_stack + 1 > 256) return fail(RGK_ERR_UNSUPPORTED, "BVH needs %u traversal-stack entries (max 256)", qb.max_stack + 1);
+    {
+        const int need = (int)qb.max_stack + 1;
+        const char* e = std::getenv("RGK_STACK_OVF"); // force the overflow variant (tests)
+        const bool ovf = need > 64 || (e && e[0] == '1' && need > 32);
+        s->tcfg.stack = ovf ? 256 : (need <= 32 ? 32 : (need <= 48 ? 48 : 64));
+        s->tcfg.lds = ovf ? 32 : s->tcfg.stack;
+        s->tcfg.ovf = nullptr;
+        if (ovf) { // 32 LDS entries + the rest per lane in global memory
+            if ((rc = s->ovf.alloc((size_t)rgk_trace_grid(s->tcfg.lds) * RGK_TRACE_BLOCK * (size_t)(s->tcfg.stack - s->tcfg.lds)))) return rc;
+            s->tcfg.ovf = s->ovf.p;
+        }
+    }
     max_depth = qb.max_depth;
 
     // ---- shading arrays
@@ -950,11 +962,11 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
                 TIMED(3, rgk_launch_raygen(st, s->dev, cam, pp, s->rayA[0].p, s->rayB[0].p, s->thr.p, s->tot.p));
                 for (uint32_t b = 0; b < prm->depth; b++) {
                     int q = b & 1;
-                    TIMED(0, rgk_launch_trace_closest(st, s->dev, s->stack, count_stats, s->rayA[q].p, s->rayB[q].p, nullptr, s->hit.p,
+                    TIMED(0, rgk_launch_trace_closest(st, s->dev, s->tcfg, count_stats, s->rayA[q].p, s->rayB[q].p, nullptr, s->hit.p,
                                                       cn + RGK_CNT_QUEUE + b, cn + RGK_CNT_FETCH_T + b, s->stats.p));
                     TIMED(2, rgk_launch_shade(st, s->dev, cam, pp, b, s->rayA[q].p, s->rayB[q].p, s->hit.p, s->thr.p, s->tot.p,
                                               s->rayA[q ^ 1].p, s->rayB[q ^ 1].p, s->shA.p, s->shB.p, s->shC.p, cn));
-                    TIMED(1, rgk_launch_trace_shadow(st, s->dev, s->stack, count_stats, s->shA.p, s->shB.p, s->shC.p, s->tot.p, nullptr,
+                    TIMED(1, rgk_launch_trace_shadow(st, s->dev, s->tcfg, count_stats, s->shA.p, s->shB.p, s->shC.p, s->tot.p, nullptr,
                                                      RGK_SHADOW_ADD, nullptr, cn + RGK_CNT_SHADOW + b, cn + RGK_CNT_FETCH_S + b, s->stats.p));
                 }
             } else {
@@ -963,22 +975,22 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
                 TIMED(3, rgk_launch_raygen_light(st, s->dev, cam, pp, s->rayA[0].p, s->rayB[0].p, s->thr.p));
                 for (uint32_t k = 0; k < R; k++) {
                     int q = k & 1;
-                    TIMED(0, rgk_launch_trace_closest(st, s->dev, s->stack, count_stats, s->rayA[q].p, s->rayB[q].p, nullptr, s->hit.p,
+                    TIMED(0, rgk_launch_trace_closest(st, s->dev, s->tcfg, count_stats, s->rayA[q].p, s->rayB[q].p, nullptr, s->hit.p,
                                                       cl + RGK_CNT_QUEUE + k, cl + RGK_CNT_FETCH_T + k, s->stats.p));
                     TIMED(2, rgk_launch_shade_light(st, s->dev, cam, pp, k, s->rayA[q].p, s->rayB[q].p, s->hit.p, s->thr.p,
                                                     s->rayA[q ^ 1].p, s->rayB[q ^ 1].p, s->shA.p, s->shB.p, s->shC.p, cl));
-                    TIMED(1, rgk_launch_trace_shadow(st, s->dev, s->stack, count_stats, s->shA.p, s->shB.p, s->shC.p, nullptr, nullptr,
+                    TIMED(1, rgk_launch_trace_shadow(st, s->dev, s->tcfg, count_stats, s->shA.p, s->shB.p, s->shC.p, nullptr, nullptr,
                                                      RGK_SHADOW_SPLAT, d_accum_rgb, cl + RGK_CNT_SHADOW + k, cl + RGK_CNT_FETCH_S + k, s->stats.p));
                 }
                 TIMED(3, rgk_launch_init_counters(st, cn, n0));
                 TIMED(3, rgk_launch_raygen_camera(st, s->dev, cam, pp, s->rayA[0].p, s->rayB[0].p, s->thr.p, s->tot.p));
                 for (uint32_t b = 0; b < prm->depth; b++) {
                     int q = b & 1;
-                    TIMED(0, rgk_launch_trace_closest(st, s->dev, s->stack, count_stats, s->rayA[q].p, s->rayB[q].p, nullptr, s->hit.p,
+                    TIMED(0, rgk_launch_trace_closest(st, s->dev, s->tcfg, count_stats, s->rayA[q].p, s->rayB[q].p, nullptr, s->hit.p,
                                                       cn + RGK_CNT_QUEUE + b, cn + RGK_CNT_FETCH_T + b, s->stats.p));
                     TIMED(2, rgk_launch_shade_bdpt(st, s->dev, cam, pp, b, s->rayA[q].p, s->rayB[q].p, s->hit.p, s->thr.p, s->tot.p,
                                                    s->rayA[q ^ 1].p, s->rayB[q ^ 1].p, s->shA.p, s->shB.p, s->shC.p, cn));
-                    TIMED(1, rgk_launch_trace_shadow(st, s->dev, s->stack, count_stats, s->shA.p, s->shB.p, s->shC.p, s->term.p, nullptr,
+                    TIMED(1, rgk_launch_trace_shadow(st, s->dev, s->tcfg, count_stats, s->shA.p, s->shB.p, s->shC.p, s->term.p, nullptr,
                                                      RGK_SHADOW_CELL, nullptr, cn + RGK_CNT_SHADOW + b, cn + RGK_CNT_FETCH_S + b, s->stats.p));
                     TIMED(3, rgk_launch_finish_vertex(st, pp, b, s->rayB[q].p, s->tot.p, cn));
                 }
@@ -1055,7 +1067,7 @@ int rgk_trace_closest(rgk_scene* s, uint32_t n, const float* rays, const int32_t
     HIPCHK(hipMemsetAsync(s->stats.p, 0, 8 * sizeof(unsigned long long), st));
     rgk_launch_init_counters(st, s->counters.p, n);
     rgk_launch_pack_rays(st, n, s->scratch_f.p, d_ign, s->rayA[0].p, s->rayB[0].p, s->nearfar.p);
-    rgk_launch_trace_closest(st, s->dev, s->stack, counters != nullptr, s->rayA[0].p, s->rayB[0].p, s->nearfar.p, s->hit.p,
+    rgk_launch_trace_closest(st, s->dev, s->tcfg, counters != nullptr, s->rayA[0].p, s->rayB[0].p, s->nearfar.p, s->hit.p,
                              s->counters.p + RGK_CNT_QUEUE, s->counters.p + RGK_CNT_FETCH_T, s->stats.p);
     rgk_hit* d_hits = (rgk_hit*)s->scratch_u.p; // 5 dwords per hit; reuses the ignore buffer after the trace
     rgk_launch_unpack_hits(st, n, s->hit.p, d_hits);
@@ -1083,7 +1095,7 @@ int rgk_trace_visibility(rgk_scene* s, uint32_t n, const float* a, const float* 
     HIPCHK(hipMemsetAsync(s->stats.p, 0, 8 * sizeof(unsigned long long), st));
     rgk_launch_init_counters(st, s->counters.p, n);
     rgk_launch_pack_visibility(st, s->dev, n, s->scratch_f.p, s->scratch_f.p + (size_t)3 * n, s->shA.p, s->shB.p, s->shC.p);
-    rgk_launch_trace_shadow(st, s->dev, s->stack, counters != nullptr, s->shA.p, s->shB.p, s->shC.p, s->tot.p, (uint8_t*)s->scratch_u.p,
+    rgk_launch_trace_shadow(st, s->dev, s->tcfg, counters != nullptr, s->shA.p, s->shB.p, s->shC.p, s->tot.p, (uint8_t*)s->scratch_u.p,
                             RGK_SHADOW_ADD, nullptr, s->counters.p + RGK_CNT_QUEUE, s->counters.p + RGK_CNT_FETCH_S, s->stats.p);
     HIPCHK(hipMemcpyAsync(visible, s->scratch_u.p, n, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));

@@ -52,9 +52,15 @@ void rgk_launch_init_counters(hipStream_t st, uint32_t* counters, uint32_t n0);
 void rgk_launch_build_halton_table(hipStream_t st, const DevScene& sc, uint32_t S, float* htab);
 void rgk_launch_raygen(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, float4* rayA, float4* rayB,
                        float4* thr, float4* tot);
-void rgk_launch_trace_closest(hipStream_t st, const DevScene& sc, int stack, bool count_stats, const float4* rayA, const float4* rayB,
+// traversal-stack configuration of a scene: entries its tree can need, how many of them live in LDS, overflow area
+struct RgkTraceCfg {
+    int stack, lds;
+    int* ovf;
+};
+int rgk_trace_grid(int lds_entries); // workgroups of a persistent trace launch (LDS-limited residency x 256 CUs)
+void rgk_launch_trace_closest(hipStream_t st, const DevScene& sc, const RgkTraceCfg& tc, bool count_stats, const float4* rayA, const float4* rayB,
                               const float2* nearfar, float4* hit, const uint32_t* count_ptr, uint32_t* fetch, unsigned long long* stats);
-void rgk_launch_trace_shadow(hipStream_t st, const DevScene& sc, int stack, bool count_stats, const float4* shA, const float4* shB,
+void rgk_launch_trace_shadow(hipStream_t st, const DevScene& sc, const RgkTraceCfg& tc, bool count_stats, const float4* shA, const float4* shB,
                              const float4* shC, float4* tot, uint8_t* vis_out, int mode, float* splat_rgb, const uint32_t* count_ptr,
                              uint32_t* fetch, unsigned long long* stats);
 void rgk_launch_raygen_light(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, float4* rayA, float4* rayB,

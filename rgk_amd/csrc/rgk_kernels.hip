@@ -348,15 +348,24 @@ __global__ void k_sampler_eval(const DevScene sc, uint32_t n, const uint32_t* se
 }
 
 // ------------------------------------------------------------------ launch wrappers (host)
-#define RGK_STACK_MID (RGK_TRACE_BLOCK <= 256 ? 48 : 32)
-#define RGK_STACK_BIG (RGK_TRACE_BLOCK <= 256 ? 64 : 32) // tuning variants with larger workgroups only serve 32-entry stacks
-static inline int trace_grid(int stack) {
-    // LDS-limited residency: STACK*256*4 B per block out of 160 KiB, 256 CUs
-    int per_cu = (160 * 1024) / (stack * RGK_TRACE_BLOCK * 4);
+int rgk_trace_grid(int lds_entries) {
+    // LDS-limited residency: entries*256*4 B per block out of 160 KiB, 256 CUs
+    int per_cu = (160 * 1024) / (lds_entries * RGK_TRACE_BLOCK * 4);
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
     return 256 * per_cu;
 }
+// (stack need, LDS entries) variants: 32/32, 48/48, 64/64 hold the whole stack in LDS (occupancy 5, 3, 2 workgroups
+// per CU); a tree that needs more than 64 entries keeps 32 in LDS and the rest per lane in global memory (256/32).
+// (64/32 instead of 48/48 on the 1 M-triangle dragon scene was measured: no gain, 1062 vs 1015 ms of shadow rays.)
+#define RGK_TRACE_DISPATCH(K, ...)                                                                   \
+    {                                                                                                \
+        const int grid = rgk_trace_grid(tc.lds);                                                     \
+        if (tc.stack <= 32) { if (count_stats) K<true, 32, 32><<<grid, RGK_TRACE_BLOCK, 0, st>>>(__VA_ARGS__); else K<false, 32, 32><<<grid, RGK_TRACE_BLOCK, 0, st>>>(__VA_ARGS__); } \
+        else if (tc.lds == 32) { if (count_stats) K<true, 256, 32><<<grid, RGK_TRACE_BLOCK, 0, st>>>(__VA_ARGS__); else K<false, 256, 32><<<grid, RGK_TRACE_BLOCK, 0, st>>>(__VA_ARGS__); } \
+        else if (tc.lds == 48) { if (count_stats) K<true, 48, 48><<<grid, RGK_TRACE_BLOCK, 0, st>>>(__VA_ARGS__); else K<false, 48, 48><<<grid, RGK_TRACE_BLOCK, 0, st>>>(__VA_ARGS__); } \
+        else { if (count_stats) K<true, 64, 64><<<grid, RGK_TRACE_BLOCK, 0, st>>>(__VA_ARGS__); else K<false, 64, 64><<<grid, RGK_TRACE_BLOCK, 0, st>>>(__VA_ARGS__); } \
+    }
 
 void rgk_launch_init_counters(hipStream_t st, uint32_t* counters, uint32_t n0) { k_init_counters<<<1, 256, 0, st>>>(counters, n0); }
 void rgk_launch_build_halton_table(hipStream_t st, const DevScene& sc, uint32_t S, float* htab) {
@@ -371,25 +380,15 @@ void rgk_launch_raygen(hipStream_t st, const DevScene& sc, const DevCamera& cam,
     k_raygen<<<grid, 256, 0, st>>>(sc, cam, pp, rayA, rayB, thr, tot);
 }
 
-void rgk_launch_trace_closest(hipStream_t st, const DevScene& sc, int stack, bool count_stats, const float4* rayA, const float4* rayB,
+void rgk_launch_trace_closest(hipStream_t st, const DevScene& sc, const RgkTraceCfg& tc, bool count_stats, const float4* rayA, const float4* rayB,
                               const float2* nearfar, float4* hit, const uint32_t* count_ptr, uint32_t* fetch, unsigned long long* stats) {
-    int grid = trace_grid(stack);
-#define L(C, S) { k_trace_closest<C, S><<<grid, RGK_TRACE_BLOCK, 0, st>>>(sc, rayA, rayB, nearfar, hit, count_ptr, fetch, stats); }
-    if (stack <= 32) { if (count_stats) L(true, 32) else L(false, 32) }
-    else if (stack <= 48 && RGK_TRACE_BLOCK <= 256) { if (count_stats) L(true, RGK_STACK_MID) else L(false, RGK_STACK_MID) }
-    else { if (count_stats) L(true, RGK_STACK_BIG) else L(false, RGK_STACK_BIG) }
-#undef L
+    RGK_TRACE_DISPATCH(k_trace_closest, sc, rayA, rayB, nearfar, hit, count_ptr, fetch, stats, tc.ovf)
 }
 
-void rgk_launch_trace_shadow(hipStream_t st, const DevScene& sc, int stack, bool count_stats, const float4* shA, const float4* shB,
+void rgk_launch_trace_shadow(hipStream_t st, const DevScene& sc, const RgkTraceCfg& tc, bool count_stats, const float4* shA, const float4* shB,
                              const float4* shC, float4* tot, uint8_t* vis_out, int mode, float* splat_rgb, const uint32_t* count_ptr,
                              uint32_t* fetch, unsigned long long* stats) {
-    int grid = trace_grid(stack);
-#define L(C, S) { k_trace_shadow<C, S><<<grid, RGK_TRACE_BLOCK, 0, st>>>(sc, shA, shB, shC, tot, vis_out, mode, splat_rgb, count_ptr, fetch, stats); }
-    if (stack <= 32) { if (count_stats) L(true, 32) else L(false, 32) }
-    else if (stack <= 48 && RGK_TRACE_BLOCK <= 256) { if (count_stats) L(true, RGK_STACK_MID) else L(false, RGK_STACK_MID) }
-    else { if (count_stats) L(true, RGK_STACK_BIG) else L(false, RGK_STACK_BIG) }
-#undef L
+    RGK_TRACE_DISPATCH(k_trace_shadow, sc, shA, shB, shC, tot, vis_out, mode, splat_rgb, count_ptr, fetch, stats, tc.ovf)
 }
 
 void rgk_launch_shade(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t bounce, const float4* rayA,

@@ -86,12 +86,14 @@ __device__ __forceinline__ float cvt_ubyte(uint32_t w, int c) { return (float)((
 // ANY = false: closest hit, results to hit[i] = {t, alpha, beta, tri}.
 // ANY = true : Scene::Visibility; vis_out[i] = visible, or (path mode) tot[slot] += radiance if visible.
 //   q0 = {o.xyz, d.x}; q1 = {d.y, d.z, ignore | far, slot}; q2 = {radiance.rgb, near} (shadow only)
-template <bool ANY, bool COUNT, int STACK>
+// STACK: entries the tree can need (host bound); LDSN <= STACK of them live in LDS, the rest -- reached only on the
+// deepest walks of a deep tree -- in a per-lane global overflow area, so that a deep tree does not halve the occupancy.
+template <bool ANY, bool COUNT, int STACK, int LDSN>
 __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float4* __restrict__ q0, const float4* __restrict__ q1,
                                                  const float4* __restrict__ q2, const float2* __restrict__ nearfar,
                                                  float4* __restrict__ hit, float4* __restrict__ tot, uint8_t* __restrict__ vis_out,
                                                  const int mode, float* __restrict__ splat_rgb,
-                                                 const uint32_t count, uint32_t* __restrict__ fetch, int* __restrict__ stack,
+                                                 const uint32_t count, uint32_t* __restrict__ fetch, int* __restrict__ stack, int* __restrict__ ovf, const uint32_t ostride,
                                                  uint32_t& n_nodes, uint32_t& n_tris) {
     const int lane = threadIdx.x & 63;
     const int stride = RGK_TRACE_BLOCK;
@@ -216,9 +218,11 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
                 // misses carry te = inf / ref = SENTINEL and sort to the back; push far -> near.
                 // Branch-free: always write the next free entry, advance only for a real child (the host
                 // sized STACK above the deepest push sequence the tree can produce, rgk_host.cpp QbvhBuilder).
-                stack[sp * stride] = ref[3]; sp += (ref[3] != STACK_SENTINEL);
-                stack[sp * stride] = ref[2]; sp += (ref[2] != STACK_SENTINEL);
-                stack[sp * stride] = ref[1]; sp += (ref[1] != STACK_SENTINEL);
+#define RGK_PUT(x) { if (LDSN >= STACK || sp < LDSN) stack[sp * stride] = (x); else ovf[(size_t)(sp - LDSN) * ostride] = (x); }
+#define RGK_POP() ((LDSN >= STACK || sp < LDSN) ? stack[sp * stride] : ovf[(size_t)(sp - LDSN) * ostride])
+                RGK_PUT(ref[3]) sp += (ref[3] != STACK_SENTINEL);
+                RGK_PUT(ref[2]) sp += (ref[2] != STACK_SENTINEL);
+                RGK_PUT(ref[1]) sp += (ref[1] != STACK_SENTINEL);
                 cur = ref[0];
             } else {
                 cur = STACK_SENTINEL; // any-hit: order is irrelevant; keep one hit child, push the rest
@@ -226,11 +230,11 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
                 for (int c = 0; c < 4; c++) {
                     if (ref[c] != STACK_SENTINEL) {
                         if (cur == STACK_SENTINEL) cur = ref[c];
-                        else if (sp < STACK) { stack[sp * stride] = ref[c]; sp++; }
+                        else if (sp < STACK) { RGK_PUT(ref[c]) sp++; }
                     }
                 }
             }
-            if (cur == STACK_SENTINEL && sp > 0) { sp--; cur = stack[sp * stride]; }
+            if (cur == STACK_SENTINEL && sp > 0) { sp--; cur = RGK_POP(); }
         }
         // ------------------------------------------------ leaf: every triangle of it.  (One triangle per scheduled step,
         // leaving when the walkers regain the majority, was measured slower: 24.2 vs 23.3 ms.)
@@ -250,7 +254,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
                 }
             }
             if (ANY && done) { cur = STACK_SENTINEL; sp = 0; }
-            else if (sp > 0) { sp--; cur = stack[sp * stride]; }
+            else if (sp > 0) { sp--; cur = RGK_POP(); }
             else cur = STACK_SENTINEL;
         }
         // ------------------------------------------------ retire finished rays
@@ -276,15 +280,15 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
 }
 
 // ------------------------------------------------------------------ K2: closest hit
-template <bool COUNT, int STACK>
+template <bool COUNT, int STACK, int LDSN>
 __global__ __launch_bounds__(RGK_TRACE_BLOCK) void k_trace_closest(const DevScene sc, const float4* __restrict__ rayA,
                                                                     const float4* __restrict__ rayB, const float2* __restrict__ nearfar,
                                                                     float4* __restrict__ hit, const uint32_t* __restrict__ count_ptr,
-                                                                    uint32_t* __restrict__ fetch, unsigned long long* __restrict__ stats) {
-    __shared__ int lds_stack[STACK * RGK_TRACE_BLOCK];
+                                                                    uint32_t* __restrict__ fetch, unsigned long long* __restrict__ stats, int* __restrict__ ovf) {
+    __shared__ int lds_stack[LDSN * RGK_TRACE_BLOCK];
     uint32_t n_nodes = 0, n_tris = 0;
-    trace_persistent<false, COUNT, STACK>(sc, rayA, rayB, nullptr, nearfar, hit, nullptr, nullptr, 0, nullptr, *count_ptr, fetch,
-                                          lds_stack + threadIdx.x, n_nodes, n_tris);
+    trace_persistent<false, COUNT, STACK, LDSN>(sc, rayA, rayB, nullptr, nearfar, hit, nullptr, nullptr, 0, nullptr, *count_ptr, fetch,
+                                          lds_stack + threadIdx.x, ovf + (blockIdx.x * RGK_TRACE_BLOCK + threadIdx.x), gridDim.x * RGK_TRACE_BLOCK, n_nodes, n_tris);
     if (COUNT) {
         atomicAdd(&stats[0], (unsigned long long)n_nodes);
         atomicAdd(&stats[1], (unsigned long long)n_tris);
@@ -293,17 +297,17 @@ __global__ __launch_bounds__(RGK_TRACE_BLOCK) void k_trace_closest(const DevScen
 
 // ------------------------------------------------------------------ K5: shadow rays + accumulate
 // shA = (o.xyz, d.x)  shB = (d.y, d.z, far, slot)  shC = (radiance.rgb, near)
-template <bool COUNT, int STACK>
+template <bool COUNT, int STACK, int LDSN>
 __global__ __launch_bounds__(RGK_TRACE_BLOCK) void k_trace_shadow(const DevScene sc, const float4* __restrict__ shA,
                                                                    const float4* __restrict__ shB, const float4* __restrict__ shC,
                                                                    float4* __restrict__ tot, uint8_t* __restrict__ vis_out,
                                                                    const int mode, float* __restrict__ splat_rgb,
                                                                    const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ fetch,
-                                                                   unsigned long long* __restrict__ stats) {
-    __shared__ int lds_stack[STACK * RGK_TRACE_BLOCK];
+                                                                   unsigned long long* __restrict__ stats, int* __restrict__ ovf) {
+    __shared__ int lds_stack[LDSN * RGK_TRACE_BLOCK];
     uint32_t n_nodes = 0, n_tris = 0;
-    trace_persistent<true, COUNT, STACK>(sc, shA, shB, shC, nullptr, nullptr, tot, vis_out, mode, splat_rgb, *count_ptr, fetch,
-                                         lds_stack + threadIdx.x, n_nodes, n_tris);
+    trace_persistent<true, COUNT, STACK, LDSN>(sc, shA, shB, shC, nullptr, nullptr, tot, vis_out, mode, splat_rgb, *count_ptr, fetch,
+                                         lds_stack + threadIdx.x, ovf + (blockIdx.x * RGK_TRACE_BLOCK + threadIdx.x), gridDim.x * RGK_TRACE_BLOCK, n_nodes, n_tris);
     if (COUNT) {
         atomicAdd(&stats[2], (unsigned long long)n_nodes);
         atomicAdd(&stats[3], (unsigned long long)n_tris);

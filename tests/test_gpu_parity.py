@@ -244,6 +244,27 @@ def test_dragon_sponza_config4_small(rd, oracle):
     assert abs(int(kg.path_rays) - int(ko.path_rays)) <= 2e-3 * ko.path_rays
 
 
+def test_deep_tree_stack_overflow_variant(rd, oracle):
+    """A tree that needs more traversal-stack entries than the 32 kept in LDS: the rest lives per lane in global memory
+    (RGK_STACK_OVF=1 forces that variant, which otherwise only serves trees needing more than 64 entries)."""
+    from rgk_amd.workloads import Workload
+    wl = Workload("dragon-sponza-1080p", scale=0.03, spp=4, dragon_level=5)
+    os.environ["RGK_STACK_OVF"] = "1"
+    try:
+        g = rd.Scene(wl.builder.to_desc())
+    finally:
+        del os.environ["RGK_STACK_OVF"]
+    o = oracle.OracleScene(wl.builder.to_desc())
+    gi = g.info()
+    assert gi.max_depth >= 11, gi.max_depth       # 3 pushes per level: more than 32 entries possible
+    lo, hi = np.array(list(gi.bbox_min)), np.array(list(gi.bbox_max))
+    oo, dd = random_rays(np.random.default_rng(9), lo, hi, 200000)
+    assert check_closest(g, o, make_rays(oo, dd), gi.epsilon, max_unexplained=5e-5) > 0.99
+    vg, _ = g.visibility(oo[:50000], oo[50000:100000])
+    vo, _ = o.visibility(oo[:50000], oo[50000:100000])
+    assert (vg != vo).mean() < 2e-3
+
+
 def test_envmap_sky_float_texture(rd, oracle):
     """Scene::GetSkyboxRay in envmap mode (scene.cpp:748-763): lat-long lookup with rotation into a float (HDR-style)
     texture -- the kind BASELINE configs[3] names but the reference checkout does not ship."""
