@@ -420,6 +420,36 @@ def test_round_properties_cornell_config2_size(rd, oracle):
     assert np.array_equal(cg, co) and np.linalg.norm(ag - ao) / np.linalg.norm(ao) <= 1e-3
 
 
+def test_round_properties_sponza_config3_full_size(rd, oracle):
+    """BASELINE configs[2] -- the benchmark workload -- at its full 1920x1080x256 spp: size-independent properties of a
+    whole round, and the oracle on a 24-tile sample of the same frame at the same 256 spp."""
+    from rgk_amd.workloads import Workload
+    wl = Workload("sponza-1080p")
+    assert (wl.xres, wl.yres, wl.multisample, wl.depth) == (1920, 1080, 256, 2)
+    g = rd.Scene(wl.builder.to_desc())
+    prm = wl.params()
+    tiles = rd.generate_task_list(wl.xres, wl.yres)
+    assert len(tiles) == 2040
+    acc, cnt, k = g.render_round(wl.camera, prm, tiles)
+    assert (cnt == 256).all() and k.paths == 1920 * 1080 * 256
+    assert np.isfinite(acc).all() and (acc >= 0).all() and acc.max() <= 256 * wl.clamp * (1 + 1e-6)
+    assert k.paths <= k.path_rays <= 2 * k.paths                         # depth 2: one or two path rays per path
+    # tile-shard invariance, the multi-GPU deal (tile i -> rank i mod 2), bit for bit
+    a2 = np.zeros_like(acc); c2 = np.zeros_like(cnt)
+    ev = (capi.Tile * ((len(tiles) + 1) // 2))(*tiles[0::2]); od = (capi.Tile * (len(tiles) // 2))(*tiles[1::2])
+    g.render_round(wl.camera, prm, ev, a2, c2); g.render_round(wl.camera, prm, od, a2, c2)
+    assert np.array_equal(acc, a2) and np.array_equal(cnt, c2)
+    # the oracle on every 85th tile of the centre-out list
+    sub = (capi.Tile * 24)(*tiles[0::85])
+    ag = np.zeros_like(acc); cg = np.zeros_like(cnt); g.render_round(wl.camera, prm, sub, ag, cg)
+    o = oracle.OracleScene(wl.builder.to_desc())
+    ao = np.zeros_like(acc); co = np.zeros_like(cnt); o.render_round(wl.camera, prm, sub, ao, co)
+    assert np.array_equal(cg, co)
+    m = co > 0
+    assert np.array_equal(ag[m], acc[m])                                 # a tile's pixels do not depend on the other tiles
+    assert np.linalg.norm(ag - ao) / np.linalg.norm(ao) <= 1e-2            # proxy Sponza: coincident-surface ties (H3)
+
+
 def test_edge_cases(rd, oracle, cornell):
     g, o = both(rd, oracle, cornell)
     prm = cornell.params()
