@@ -127,7 +127,7 @@ struct DevScene {
     const float4* texels; // RGBA float, A unused: one 16-byte load per texel
     const uint32_t* texels8; // RGBA8, A unused: one dword per texel, decoded through `luts`
     const float* luts;
-    uint32_t n_lut_floats;
+    uint32_t n_lut_floats, n_materials;
     const DevPointLight* pointlights;
     const DevArealLight* areal;
     const DevArealTri* areal_tris;

@@ -232,10 +232,25 @@ __device__ __forceinline__ uint32_t tex_col(const TexRef t, int x) { return (uin
 // (lut_lds_fill at kernel entry; launch with RGK_LDS_LUT_FLOATS * 4 bytes of dynamic LDS): the three dependent
 // table loads per texel were 7 % of the shade kernel.
 #define RGK_LDS_LUT_FLOATS 512u
+#define RGK_LDS_MATERIALS 64u // the first material records follow the tables (the hot loop's third dependent load)
+#define RGK_LDS_SHADE_BYTES ((RGK_LDS_LUT_FLOATS + RGK_LDS_MATERIALS * (uint32_t)(sizeof(DevMaterial) / 4)) * 4u)
 extern __shared__ float rgk_lut_lds[];
 __device__ __forceinline__ void lut_lds_fill(const DevScene& sc) {
     for (uint32_t k = threadIdx.x; k < RGK_LDS_LUT_FLOATS; k += blockDim.x) rgk_lut_lds[k] = k < sc.n_lut_floats ? gld_f32(sc.luts, k << 2) : 0.f;
+    const uint32_t nm = (sc.n_materials < RGK_LDS_MATERIALS ? sc.n_materials : RGK_LDS_MATERIALS) * (uint32_t)(sizeof(DevMaterial) / 4);
+    for (uint32_t k = threadIdx.x; k < nm; k += blockDim.x) rgk_lut_lds[RGK_LDS_LUT_FLOATS + k] = gld_f32(sc.materials, k << 2);
     __syncthreads();
+}
+__device__ __forceinline__ DevMaterial mat_load(const DevScene& sc, uint32_t id) {
+    if (id < RGK_LDS_MATERIALS) {
+        DevMaterial m;
+        const float* src = rgk_lut_lds + RGK_LDS_LUT_FLOATS + id * (uint32_t)(sizeof(DevMaterial) / 4);
+        float* dst = reinterpret_cast<float*>(&m);
+#pragma unroll
+        for (uint32_t k = 0; k < sizeof(DevMaterial) / 4; k++) dst[k] = src[k];
+        return m;
+    }
+    return gld_rec<DevMaterial>(sc.materials, id * (uint32_t)sizeof(DevMaterial));
 }
 __device__ __forceinline__ f3 texel_at(const DevScene& sc, const TexRef t, uint32_t idx) { // idx = tex_row + tex_col
     if (tex_kind(t) == RGK_TEX_RGB8) { // the bytes the 8-bit loaders keep + the table that makes them the reference's floats
@@ -725,7 +740,7 @@ __device__ __forceinline__ void surface_point(const DevScene& sc, float bumpmap_
     const uint32_t tsr = (uint32_t)tri * (uint32_t)sizeof(TriShade);
     const float4 g0 = gld_f4(sc.tri_shade, tsr), g1 = gld_f4(sc.tri_shade, tsr + 16u), g2 = gld_f4(sc.tri_shade, tsr + 32u);
     v.mat_id = gld_u32(sc.tri_shade, tsr + 96u);
-    v.mat = gld_rec<DevMaterial>(sc.materials, v.mat_id * (uint32_t)sizeof(DevMaterial));
+    v.mat = mat_load(sc, v.mat_id);
     const float al = h.y, be = h.z;
     const float ia = 1.0f - al - be, ib = al, ic = be; // Intersection::a,b,c scene_intersect.cpp:280-283
     v.Vr = -d;

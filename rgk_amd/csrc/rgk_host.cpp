@@ -783,7 +783,7 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
     { const char* e = std::getenv("RGK_WALK_Q"); ds.walk_q = e ? (uint32_t)std::atoi(e) : 3u; }
     if (std::getenv("RGK_DEBUG_BVH")) std::fprintf(stderr, "[rgk] bvh4 nodes %zu max_stack %u max_depth %u refs %zu of %u triangles\n", qb.out.size(), qb.max_stack, qb.max_depth, leaf_recs.size(), nt);
     ds.tris = s->tris.p; ds.tri_shade = s->tri_shade.p;
-    ds.materials = s->materials.p; ds.texels = s->texels.p; ds.texels8 = s->texels8.p; ds.luts = s->luts.p; ds.n_lut_floats = (uint32_t)luts.size();
+    ds.materials = s->materials.p; ds.texels = s->texels.p; ds.texels8 = s->texels8.p; ds.luts = s->luts.p; ds.n_lut_floats = (uint32_t)luts.size(); ds.n_materials = (uint32_t)mats.size();
     ds.pointlights = s->pointlights.p; ds.areal = s->areal.p; ds.areal_tris = s->areal_tris.p;
     ds.ltc = s->ltc.p; ds.hdims = s->hdims.p; ds.hperm = s->hperm.p;
     ds.n_pointlights = (uint32_t)pls.size(); ds.n_areal = (uint32_t)als.size();
