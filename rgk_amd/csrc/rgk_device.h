@@ -270,9 +270,6 @@ __device__ __forceinline__ f3 texel_at(const DevScene& sc, const TexRef t, uint3
 __device__ __forceinline__ f3 tex_get(const DevScene& sc, const TexRef t, float2 uv) {
     if (tex_kind(t) == RGK_TEXREF_NONE) return mk3(0.f, 0.f, 0.f);
     if (tex_kind(t) == RGK_TEX_SOLID) return mk3(__uint_as_float(t.a), __uint_as_float(t.b), __uint_as_float(t.c));
-#ifdef RGK_EXP_NOTEX
-    return mk3(0.5f + uv.x * 1e-3f, 0.5f, 0.5f);
-#endif
     const int xsize = (int)(t.a & 0xffffu), ysize = (int)(t.a >> 16);
     float x = glm_repeat(uv.x) * xsize - 0.5f;
     float y = glm_repeat(uv.y) * ysize - 0.5f;
@@ -296,9 +293,6 @@ __device__ __forceinline__ f3 tex_get(const DevScene& sc, const TexRef t, float2
 __device__ __forceinline__ void tex_slopes(const DevScene& sc, const TexRef t, float2 uv, float& right, float& bottom) {
     right = 0.f; bottom = 0.f;
     if (tex_kind(t) != RGK_TEX_RGB32F && tex_kind(t) != RGK_TEX_RGB8) return;
-#if defined(RGK_EXP_NOTEX) || defined(RGK_EXP_NOBUMP)
-    right = uv.x * 1e-3f; bottom = uv.y * 1e-3f; return;
-#endif
     const int xsize = (int)(t.a & 0xffffu), ysize = (int)(t.a >> 16);
     int x = (int)(glm_repeat(uv.x) * xsize - 0.5f);
     int y = (int)(glm_repeat(uv.y) * ysize - 0.5f);
@@ -330,9 +324,6 @@ __device__ __forceinline__ LtcM ltc_bilinear(const void* ltc, uint32_t tab, floa
     const int s = 63;
     int t1 = (int)floorf(t * s), t2 = t1 + 1;
     int a1 = (int)floorf(a * s), a2 = a1 + 1;
-#ifdef RGK_EXP_NOLTC
-    { LtcM r; r.m0 = 1.f + t * 0.1f; r.m2 = 0.1f * a; r.m4 = 1.f; r.m6 = -0.1f; r.m8 = 1.f; r.amp = 0.9f; return r; }
-#endif
     const uint32_t o11 = tab + ((uint32_t)(a1 + t1 * 64) << 5), o12 = tab + ((uint32_t)(a2 + t1 * 64) << 5);
     const uint32_t o21 = tab + ((uint32_t)(a1 + t2 * 64) << 5), o22 = tab + ((uint32_t)(a2 + t2 * 64) << 5);
     const float4 m11 = gld_f4(ltc, o11), m12 = gld_f4(ltc, o12), m21 = gld_f4(ltc, o21), m22 = gld_f4(ltc, o22);

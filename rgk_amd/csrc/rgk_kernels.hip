@@ -394,9 +394,9 @@ void rgk_launch_trace_shadow(hipStream_t st, const DevScene& sc, const RgkTraceC
 void rgk_launch_shade(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t bounce, const float4* rayA,
                       const float4* rayB, const float4* hit, float4* thr, float4* tot, float4* nextA, float4* nextB, float4* shA,
                       float4* shB, float4* shC, uint32_t* counters) {
-    k_shade<false><<<256 * 4 * (512 / RGK_SHADE_BLOCK), RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
+    k_shade<false><<<256 * 4 * 512 / RGK_SHADE_BLOCK, RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
     // the vertices the first launch listed (materials on the generic BxDF route); returns at once when there are none
-    k_shade<true><<<256 * 2 * (512 / RGK_SHADE_BLOCK), RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
+    k_shade<true><<<256 * 2 * 512 / RGK_SHADE_BLOCK, RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
 }
 
 void rgk_launch_resolve(hipStream_t st, const PassParams& pp, const float4* tot, float4* pixsum, float* accum_rgb, uint32_t* accum_count) {
@@ -433,12 +433,12 @@ void rgk_launch_raygen_camera(hipStream_t st, const DevScene& sc, const DevCamer
 void rgk_launch_shade_light(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t k, const float4* rayA,
                             const float4* rayB, const float4* hit, float4* thr, float4* nextA, float4* nextB, float4* shA, float4* shB,
                             float4* shC, uint32_t* counters) {
-    k_shade_light<<<256 * 4 * (512 / RGK_SHADE_BLOCK), RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, k, rayA, rayB, hit, thr, nextA, nextB, shA, shB, shC, counters);
+    k_shade_light<<<256 * 4 * 512 / RGK_SHADE_BLOCK, RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, k, rayA, rayB, hit, thr, nextA, nextB, shA, shB, shC, counters);
 }
 void rgk_launch_shade_bdpt(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t bounce,
                            const float4* rayA, const float4* rayB, const float4* hit, float4* thr, float4* tot, float4* nextA, float4* nextB,
                            float4* shA, float4* shB, float4* shC, uint32_t* counters) {
-    k_shade_bdpt<<<256 * 4 * (512 / RGK_SHADE_BLOCK), RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
+    k_shade_bdpt<<<256 * 4 * 512 / RGK_SHADE_BLOCK, RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
 }
 void rgk_launch_finish_vertex(hipStream_t st, const PassParams& pp, uint32_t bounce, const float4* rayB, float4* tot, const uint32_t* counters) {
     k_finish_vertex<<<256 * 8, 256, 0, st>>>(pp, bounce, rayB, tot, counters);
