@@ -363,8 +363,8 @@ struct rgk_scene {
     DevBuf<DevArealLight> areal;
     DevBuf<DevArealTri> areal_tris;
     DevBuf<float4> ltc;
-    DevBuf<DevScene> self;
-    DevBuf<uint32_t> generic; // queue indices left to the generic-BxDF shade launch // device-resident copy of `dev` (DevScene::self)
+    DevBuf<DevScene> self;    // device-resident copy of `dev` (DevScene::self)
+    DevBuf<uint32_t> generic; // queue indices left to the generic-BxDF shade launch
     DevBuf<DevHaltonDim> hdims;
     DevBuf<uint16_t> hperm;
     // workspace
@@ -389,7 +389,7 @@ struct rgk_scene {
         hdims.release(); hperm.release();
         for (int i = 0; i < 2; i++) { rayA[i].release(); rayB[i].release(); }
         hit.release(); thr.release(); tot.release(); shA.release(); shB.release(); shC.release(); pixsum.release();
-        light.release(); htab.release(); lstart.release(); lv.release(); term.release(); vfin.release(); vemit.release();
+        light.release(); generic.release(); htab.release(); lstart.release(); lv.release(); term.release(); vfin.release(); vemit.release();
         nearfar.release(); counters.release(); pix_xy.release(); pix_seed.release(); stats.release();
         scratch_f.release(); scratch_u.release();
         if (stream) (void)hipStreamDestroy(stream);
