@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_raygen(const DevScene sc, const DevCame
         pp.light[slot] = make_float4(lpos.x, lpos.y, lpos.z, __uint_as_float(lcode));
         rayA[slot] = make_float4(o.x, o.y, o.z, d.x);
         rayB[slot] = make_float4(d.y, d.z, __uint_as_float(0xffffffffu), __uint_as_float(slot));
-        thr[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(1u << 16)); // n = 0, 1-D counter = 1
+        // thr[slot] is implicit until the first vertex writes it: {1, 1, 1 | n = 0, 1-D counter = 1} (k_shade, bounce 0)
         tot[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, RGK_SHADE_WAVES) void k_shade(cons
             const float4 a = rayA[i], b = rayB[i], h = hit[i];
             const uint32_t slot = __float_as_uint(b.w);
             const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
-            float4 st = thr[slot];
+            const float4 st = bounce == 0 ? make_float4(1.f, 1.f, 1.f, __uint_as_float(1u << 16)) : thr[slot]; // k_raygen leaves it implicit
             f3 cum = mk3(st.x, st.y, st.z);
             uint32_t bits = __float_as_uint(st.w);
             uint32_t n = (bits & 0xffffu) + 1u; // n++ at loop top, reference path_tracer.cpp:123
