@@ -3,7 +3,8 @@
 //   * scene commit: the OUTPUTS of Scene::Commit the hot path reads (reference
 //     src/scene.cpp:294-400): triangle planes, areal-light tables sorted by area,
 //     light powers, epsilon = 1e-5 * bbox diagonal, epsilon-padded bbox;
-//   * the build's own accelerator (binned-SAH BVH2, 64-byte nodes) -- the reference's
+//   * the build's own accelerator (binned-SAH BVH2 over pre-split references, collapsed to a
+//     quantised 4-wide BVH with one 64-byte line per node) -- the reference's
 //     kd-tree construction (scene.cpp:431-657) is out of scope, only its nearest-hit
 //     semantics are kept;
 //   * the round driver: tiles -> per-pixel seeds (a2) -> passes of paths resident in
