@@ -214,6 +214,19 @@ def test_cornell_image_parity(rd, oracle):
     assert kg.shadow_rays <= ko.shadow_rays                                        # zero-radiance shadow rays are skipped
 
 
+def test_cornell_against_the_frozen_oracle_image(rd):
+    """The committed expected accumulator of BASELINE configs[0] at half resolution (tests/golden/cornell_config0_half.npz,
+    rendered by the oracle, generator tools/make_fixtures.py): no oracle code runs in this test."""
+    from rgk_amd.workloads import Workload
+    z = np.load(os.path.join(ROOT, "tests", "golden", "cornell_config0_half.npz"))
+    wl = Workload("cornell-256", scale=0.5)
+    g = rd.Scene(wl.builder.to_desc())
+    acc, cnt, k = g.render_round(wl.camera, wl.params(), rd.generate_task_list(wl.xres, wl.yres))
+    assert np.array_equal(cnt, z["count"]) and k.paths == int(z["counters"][0])
+    assert abs(int(k.path_rays) - int(z["counters"][1])) <= 1e-4 * int(z["counters"][1])
+    assert np.linalg.norm(acc - z["accum"]) / np.linalg.norm(z["accum"]) <= 1e-3
+
+
 def test_sponza_proxy_image_parity(rd, oracle, sponza_small):
     """LTC-GGX + diffuse, bilinear textures, bump mapping, point light, constant sky."""
     img, ref, kg, ko = render_both(rd, oracle, sponza_small)

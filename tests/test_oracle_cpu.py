@@ -418,3 +418,16 @@ def test_reference_scene_fixture_renders_and_regenerates(oracle, name):
         assert t0["kind"] == t1["kind"]
         if t0["kind"] != 0:
             assert np.array_equal(t0["data"], t1["data"])
+
+
+def test_oracle_reproduces_the_frozen_config0_image(oracle):
+    """tests/golden/cornell_config0_half.npz: the oracle's accumulator for BASELINE configs[0] at half resolution,
+    frozen when the GPU parity was established.  A change in the oracle shows up here (up to libm's last bits)."""
+    from rgk_amd.workloads import Workload
+    z = np.load(os.path.join(ROOT, "tests", "golden", "cornell_config0_half.npz"))
+    wl = Workload("cornell-256", scale=0.5)
+    o = oracle.OracleScene(wl.builder.to_desc())
+    acc, cnt, k = o.render_round(wl.camera, wl.params(), oracle.generate_task_list(wl.xres, wl.yres))
+    assert np.array_equal(cnt, z["count"])
+    assert [k.paths, k.path_rays, k.shadow_rays] == [int(v) for v in z["counters"]]
+    assert np.linalg.norm(acc - z["accum"]) / np.linalg.norm(z["accum"]) <= 1e-6

@@ -8,6 +8,7 @@ needs /root/reference).  Fixtures are DATA: inputs and expected outputs.
   rgk_amd/data/cornell_scene.npz  the flat arrays ConfigJSON::Install* would hand to Scene for
                      scenes/cornell-box.json (built by rgk_amd.config from the reference's
                      config file), plus camera / render parameters.
+  cornell_config0_half.npz  the oracle's accumulator for BASELINE configs[0] at half resolution (128x128x16 spp).
   scene_<name>.npz   the same for the other scenes the reference ships complete (mesh + textures):
                      rubiks-bump (PNG texture + bump map, point light), cube3 (8966 faces, global
                      ltc_beckmann override, sphere light), box6 (17 k triangles with uv, emissive
@@ -71,9 +72,23 @@ def reference_scene(name):
     print(os.path.basename(out), len(sb.V), "vertices", len(sb.F), "triangles", os.path.getsize(out) // 1024, "KiB")
 
 
+def cornell_image():
+    """BASELINE configs[0] (cornell 256x256x16, scenes/cornell-box.json) at half resolution, one round, rendered by
+    the oracle: the frozen expected accumulator both the oracle (drift guard) and the GPU are compared with."""
+    from oracle import rgk_oracle as O
+    from rgk_amd.workloads import Workload
+    wl = Workload("cornell-256", scale=0.5)
+    o = O.OracleScene(wl.builder.to_desc())
+    acc, cnt, k = o.render_round(wl.camera, wl.params(), O.generate_task_list(wl.xres, wl.yres))
+    np.savez_compressed(os.path.join(GOLD, "cornell_config0_half.npz"), accum=acc, count=cnt,
+                        counters=np.array([k.paths, k.path_rays, k.shadow_rays], dtype=np.uint64))
+    print("cornell_config0_half.npz", acc.shape, int(k.paths), "paths")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     halton()
     cornell()
+    cornell_image()
     for n in REFERENCE_SCENES:
         reference_scene(n)
