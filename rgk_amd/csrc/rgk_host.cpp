@@ -949,6 +949,20 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
     if ((rc = s->htab.alloc((size_t)192 * prm->multisample))) return rc;
     TIMED(3, rgk_launch_build_halton_table(st, s->dev, prm->multisample, s->htab.p));
     pp.htab = s->htab.p; pp.light = s->light.p; pp.generic = s->generic.p;
+    // Deep path loops (depth > 12): the length of the next queue is read back every other bounce from the fourth on; it
+    // bounds the grids of the following launches (queues only shrink) and ends the loop once no path is left.
+    auto queue_len = [&](const uint32_t* dptr, uint32_t& out) -> int {
+        // the copy lands in pinned memory; polling it costs microseconds where hipStreamSynchronize was measured at
+        // 2-3 ms per call (blocking wait), more than the launches it saves
+        volatile uint32_t* h = s->h_counters;
+        h[0] = 0xffffffffu; // never a queue length (queues hold < 2^30 entries)
+        HIPCHK(hipMemcpyAsync(s->h_counters, dptr, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        for (uint64_t spins = 0; h[0] == 0xffffffffu; spins++)
+            if ((spins & 0xfffff) == 0xfffff && hipStreamQuery(st) == hipSuccess && h[0] == 0xffffffffu) { HIPCHK(hipStreamSynchronize(st)); break; }
+        out = h[0];
+        return 0;
+    };
+    const bool track = prm->depth > 12; // measured: depth 10 loses 4 % to the read-backs, depth 40 gains 4 %
     for (size_t j0 = 0; j0 < P; j0 += npix_pass) {
         pp.j0 = (uint32_t)j0;
         pp.npix = (uint32_t)std::min(npix_pass, P - j0);
@@ -961,17 +975,21 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
             if (R == 0) {
                 TIMED(3, rgk_launch_init_counters(st, cn, n0));
                 TIMED(3, rgk_launch_raygen(st, s->dev, cam, pp, s->rayA[0].p, s->rayB[0].p, s->thr.p, s->tot.p));
-                for (uint32_t b = 0; b < prm->depth; b++) {
+                uint32_t ub = n0; // upper bound on bounce b's queue
+                for (uint32_t b = 0; b < prm->depth && ub > 0; b++) {
                     int q = b & 1;
+                    rgk_launch_set_bound(ub, ub);
                     TIMED(0, rgk_launch_trace_closest(st, s->dev, s->tcfg, count_stats, s->rayA[q].p, s->rayB[q].p, nullptr, s->hit.p,
                                                       cn + RGK_CNT_QUEUE + b, cn + RGK_CNT_FETCH_T + b, s->stats.p));
                     TIMED(2, rgk_launch_shade(st, s->dev, cam, pp, b, s->rayA[q].p, s->rayB[q].p, s->hit.p, s->thr.p, s->tot.p,
                                               s->rayA[q ^ 1].p, s->rayB[q ^ 1].p, s->shA.p, s->shB.p, s->shC.p, cn));
                     TIMED(1, rgk_launch_trace_shadow(st, s->dev, s->tcfg, count_stats, s->shA.p, s->shB.p, s->shC.p, s->tot.p, nullptr,
                                                      RGK_SHADOW_ADD, nullptr, cn + RGK_CNT_SHADOW + b, cn + RGK_CNT_FETCH_S + b, s->stats.p));
+                    if (track && b >= 3 && (b & 1) && b + 1 < prm->depth && (rc = queue_len(cn + RGK_CNT_QUEUE + b + 1, ub))) return rc;
                 }
             } else {
                 // light sub-path first (its sampler dimensions are fixed), splats straight into the accumulator
+                rgk_launch_set_bound(n0, n0);
                 TIMED(3, rgk_launch_init_counters(st, cl, n0));
                 TIMED(3, rgk_launch_raygen_light(st, s->dev, cam, pp, s->rayA[0].p, s->rayB[0].p, s->thr.p));
                 for (uint32_t k = 0; k < R; k++) {
@@ -985,8 +1003,10 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
                 }
                 TIMED(3, rgk_launch_init_counters(st, cn, n0));
                 TIMED(3, rgk_launch_raygen_camera(st, s->dev, cam, pp, s->rayA[0].p, s->rayB[0].p, s->thr.p, s->tot.p));
-                for (uint32_t b = 0; b < prm->depth; b++) {
+                uint32_t ub = n0;
+                for (uint32_t b = 0; b < prm->depth && ub > 0; b++) {
                     int q = b & 1;
+                    rgk_launch_set_bound(ub, (uint32_t)std::min<uint64_t>((uint64_t)ub * (R + 1), 0xffffffffull));
                     TIMED(0, rgk_launch_trace_closest(st, s->dev, s->tcfg, count_stats, s->rayA[q].p, s->rayB[q].p, nullptr, s->hit.p,
                                                       cn + RGK_CNT_QUEUE + b, cn + RGK_CNT_FETCH_T + b, s->stats.p));
                     TIMED(2, rgk_launch_shade_bdpt(st, s->dev, cam, pp, b, s->rayA[q].p, s->rayB[q].p, s->hit.p, s->thr.p, s->tot.p,
@@ -994,6 +1014,7 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
                     TIMED(1, rgk_launch_trace_shadow(st, s->dev, s->tcfg, count_stats, s->shA.p, s->shB.p, s->shC.p, s->term.p, nullptr,
                                                      RGK_SHADOW_CELL, nullptr, cn + RGK_CNT_SHADOW + b, cn + RGK_CNT_FETCH_S + b, s->stats.p));
                     TIMED(3, rgk_launch_finish_vertex(st, pp, b, s->rayB[q].p, s->tot.p, cn));
+                    if (track && b >= 3 && (b & 1) && b + 1 < prm->depth && (rc = queue_len(cn + RGK_CNT_QUEUE + b + 1, ub))) return rc;
                 }
             }
             TIMED(3, rgk_launch_resolve(st, pp, s->tot.p, s->pixsum.p, d_accum_rgb, d_accum_count));
@@ -1068,6 +1089,7 @@ int rgk_trace_closest(rgk_scene* s, uint32_t n, const float* rays, const int32_t
     HIPCHK(hipMemsetAsync(s->stats.p, 0, 8 * sizeof(unsigned long long), st));
     rgk_launch_init_counters(st, s->counters.p, n);
     rgk_launch_pack_rays(st, n, s->scratch_f.p, d_ign, s->rayA[0].p, s->rayB[0].p, s->nearfar.p);
+    rgk_launch_set_bound(n, n);
     rgk_launch_trace_closest(st, s->dev, s->tcfg, counters != nullptr, s->rayA[0].p, s->rayB[0].p, s->nearfar.p, s->hit.p,
                              s->counters.p + RGK_CNT_QUEUE, s->counters.p + RGK_CNT_FETCH_T, s->stats.p);
     rgk_hit* d_hits = (rgk_hit*)s->scratch_u.p; // 5 dwords per hit; reuses the ignore buffer after the trace
@@ -1096,6 +1118,7 @@ int rgk_trace_visibility(rgk_scene* s, uint32_t n, const float* a, const float* 
     HIPCHK(hipMemsetAsync(s->stats.p, 0, 8 * sizeof(unsigned long long), st));
     rgk_launch_init_counters(st, s->counters.p, n);
     rgk_launch_pack_visibility(st, s->dev, n, s->scratch_f.p, s->scratch_f.p + (size_t)3 * n, s->shA.p, s->shB.p, s->shC.p);
+    rgk_launch_set_bound(n, n);
     rgk_launch_trace_shadow(st, s->dev, s->tcfg, counters != nullptr, s->shA.p, s->shB.p, s->shC.p, s->tot.p, (uint8_t*)s->scratch_u.p,
                             RGK_SHADOW_ADD, nullptr, s->counters.p + RGK_CNT_QUEUE, s->counters.p + RGK_CNT_FETCH_S, s->stats.p);
     HIPCHK(hipMemcpyAsync(visible, s->scratch_u.p, n, hipMemcpyDeviceToHost, st));

@@ -57,7 +57,9 @@ struct RgkTraceCfg {
     int stack, lds;
     int* ovf;
 };
-int rgk_trace_grid(int lds_entries); // workgroups of a persistent trace launch (LDS-limited residency x 256 CUs)
+int rgk_trace_grid(int lds_entries);
+// upper bounds on the queue lengths the following launches consume (grids shrink accordingly); 0xffffffff = unknown
+void rgk_launch_set_bound(uint32_t items, uint32_t shadow_items); // workgroups of a persistent trace launch (LDS-limited residency x 256 CUs)
 void rgk_launch_trace_closest(hipStream_t st, const DevScene& sc, const RgkTraceCfg& tc, bool count_stats, const float4* rayA, const float4* rayB,
                               const float2* nearfar, float4* hit, const uint32_t* count_ptr, uint32_t* fetch, unsigned long long* stats);
 void rgk_launch_trace_shadow(hipStream_t st, const DevScene& sc, const RgkTraceCfg& tc, bool count_stats, const float4* shA, const float4* shB,

@@ -348,6 +348,16 @@ __global__ void k_sampler_eval(const DevScene sc, uint32_t n, const uint32_t* se
 }
 
 // ------------------------------------------------------------------ launch wrappers (host)
+// Upper bound on the length of the queues the next launches will consume (the host reads a queue counter back every
+// few bounces of a deep path loop): a 40-bounce round ends in dozens of launches over a few hundred rays, and a
+// full persistent grid of 3000 waves then costs more in work-fetch atomics and LDS fills than the rays themselves.
+static thread_local uint32_t g_bound = 0xffffffffu, g_bound_shadow = 0xffffffffu;
+void rgk_launch_set_bound(uint32_t items, uint32_t shadow_items) { g_bound = items; g_bound_shadow = shadow_items; }
+static inline int bounded_grid(int full, uint32_t items, uint32_t per_block) {
+    const uint64_t need = ((uint64_t)items + per_block - 1) / per_block;
+    return (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)full, need));
+}
+
 int rgk_trace_grid(int lds_entries) {
     // LDS-limited residency: entries*256*4 B per block out of 160 KiB, 256 CUs
     int per_cu = (160 * 1024) / (lds_entries * RGK_TRACE_BLOCK * 4);
@@ -358,9 +368,9 @@ int rgk_trace_grid(int lds_entries) {
 // (stack need, LDS entries) variants: 32/32, 48/48, 64/64 hold the whole stack in LDS (occupancy 5, 3, 2 workgroups
 // per CU); a tree that needs more than 64 entries keeps 32 in LDS and the rest per lane in global memory (256/32).
 // (64/32 instead of 48/48 on the 1 M-triangle dragon scene was measured: no gain, 1062 vs 1015 ms of shadow rays.)
-#define RGK_TRACE_DISPATCH(K, ...)                                                                   \
+#define RGK_TRACE_DISPATCH(K, BOUND, ...)                                                                   \
     {                                                                                                \
-        const int grid = rgk_trace_grid(tc.lds);                                                     \
+        const int grid = bounded_grid(rgk_trace_grid(tc.lds), BOUND, RGK_TRACE_BLOCK);               \
         if (tc.stack <= 32) { if (count_stats) K<true, 32, 32><<<grid, RGK_TRACE_BLOCK, 0, st>>>(__VA_ARGS__); else K<false, 32, 32><<<grid, RGK_TRACE_BLOCK, 0, st>>>(__VA_ARGS__); } \
         else if (tc.lds == 32) { if (count_stats) K<true, 256, 32><<<grid, RGK_TRACE_BLOCK, 0, st>>>(__VA_ARGS__); else K<false, 256, 32><<<grid, RGK_TRACE_BLOCK, 0, st>>>(__VA_ARGS__); } \
         else if (tc.lds == 48) { if (count_stats) K<true, 48, 48><<<grid, RGK_TRACE_BLOCK, 0, st>>>(__VA_ARGS__); else K<false, 48, 48><<<grid, RGK_TRACE_BLOCK, 0, st>>>(__VA_ARGS__); } \
@@ -382,21 +392,21 @@ void rgk_launch_raygen(hipStream_t st, const DevScene& sc, const DevCamera& cam,
 
 void rgk_launch_trace_closest(hipStream_t st, const DevScene& sc, const RgkTraceCfg& tc, bool count_stats, const float4* rayA, const float4* rayB,
                               const float2* nearfar, float4* hit, const uint32_t* count_ptr, uint32_t* fetch, unsigned long long* stats) {
-    RGK_TRACE_DISPATCH(k_trace_closest, sc, rayA, rayB, nearfar, hit, count_ptr, fetch, stats, tc.ovf)
+    RGK_TRACE_DISPATCH(k_trace_closest, g_bound, sc, rayA, rayB, nearfar, hit, count_ptr, fetch, stats, tc.ovf)
 }
 
 void rgk_launch_trace_shadow(hipStream_t st, const DevScene& sc, const RgkTraceCfg& tc, bool count_stats, const float4* shA, const float4* shB,
                              const float4* shC, float4* tot, uint8_t* vis_out, int mode, float* splat_rgb, const uint32_t* count_ptr,
                              uint32_t* fetch, unsigned long long* stats) {
-    RGK_TRACE_DISPATCH(k_trace_shadow, sc, shA, shB, shC, tot, vis_out, mode, splat_rgb, count_ptr, fetch, stats, tc.ovf)
+    RGK_TRACE_DISPATCH(k_trace_shadow, g_bound_shadow, sc, shA, shB, shC, tot, vis_out, mode, splat_rgb, count_ptr, fetch, stats, tc.ovf)
 }
 
 void rgk_launch_shade(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t bounce, const float4* rayA,
                       const float4* rayB, const float4* hit, float4* thr, float4* tot, float4* nextA, float4* nextB, float4* shA,
                       float4* shB, float4* shC, uint32_t* counters) {
-    k_shade<false><<<256 * 4 * 512 / RGK_SHADE_BLOCK, RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
+    k_shade<false><<<bounded_grid(256 * 4 * 512 / RGK_SHADE_BLOCK, g_bound, RGK_SHADE_BLOCK), RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
     // the vertices the first launch listed (materials on the generic BxDF route); returns at once when there are none
-    k_shade<true><<<256 * 2 * 512 / RGK_SHADE_BLOCK, RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
+    k_shade<true><<<bounded_grid(256 * 2 * 512 / RGK_SHADE_BLOCK, g_bound, RGK_SHADE_BLOCK), RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
 }
 
 void rgk_launch_resolve(hipStream_t st, const PassParams& pp, const float4* tot, float4* pixsum, float* accum_rgb, uint32_t* accum_count) {
@@ -438,8 +448,8 @@ void rgk_launch_shade_light(hipStream_t st, const DevScene& sc, const DevCamera&
 void rgk_launch_shade_bdpt(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t bounce,
                            const float4* rayA, const float4* rayB, const float4* hit, float4* thr, float4* tot, float4* nextA, float4* nextB,
                            float4* shA, float4* shB, float4* shC, uint32_t* counters) {
-    k_shade_bdpt<<<256 * 4 * 512 / RGK_SHADE_BLOCK, RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
+    k_shade_bdpt<<<bounded_grid(256 * 4 * 512 / RGK_SHADE_BLOCK, g_bound, RGK_SHADE_BLOCK), RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
 }
 void rgk_launch_finish_vertex(hipStream_t st, const PassParams& pp, uint32_t bounce, const float4* rayB, float4* tot, const uint32_t* counters) {
-    k_finish_vertex<<<256 * 8, 256, 0, st>>>(pp, bounce, rayB, tot, counters);
+    k_finish_vertex<<<bounded_grid(256 * 8, g_bound, 256), 256, 0, st>>>(pp, bounce, rayB, tot, counters);
 }
