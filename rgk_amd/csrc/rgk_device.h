@@ -383,7 +383,7 @@ __device__ __forceinline__ f3 ltc_random(const void* ltc, uint32_t tab, f3 Vi, f
 
 // ------------------------------------------------------------------ BxDFs (a11)
 // FresnellDielectric, reference src/bxdf/bxdf.cpp:332-355
-__device__ inline void fresnel_dielectric(float eta, float cosTheta, float& R, float& cosT) {
+__device__ __forceinline__ void fresnel_dielectric(float eta, float cosTheta, float& R, float& cosT) {
     if (cosTheta < 0.0f) { eta = 1.0f / eta; cosTheta = -cosTheta; }
     float sinThetaTSq = eta * eta * (1.0f - cosTheta * cosTheta);
     if (sinThetaTSq > 1.0f) { R = 1.0f; cosT = 0.0f; return; }
@@ -395,7 +395,7 @@ __device__ inline void fresnel_dielectric(float eta, float cosTheta, float& R, f
 }
 
 // BxDF::value of a non-mix material, reference src/bxdf/bxdf.cpp:192-423, bxdf.hpp:107-159
-__device__ inline f3 bxdf_value_leaf(const DevScene& sc, const DevMaterial& m, f3 Vi, f3 Vr, float2 uv) {
+__device__ __forceinline__ f3 bxdf_value_leaf(const DevScene& sc, const DevMaterial& m, f3 Vi, f3 Vr, float2 uv) {
     const f3 zero = mk3(0.f, 0.f, 0.f);
     switch (m.kind) {
     case RGK_BXDF_DIFFUSE:
@@ -441,7 +441,7 @@ __device__ inline f3 bxdf_value_leaf(const DevScene& sc, const DevMaterial& m, f
 }
 // BxDFMix::value recurses once per level (reference bxdf.cpp:235-239); the device walks an
 // explicit stack so nested mixes up to 4 deep are evaluated without recursion.
-__device__ inline f3 bxdf_value(const DevScene& sc, int mat, f3 Vi, f3 Vr, float2 uv) {
+__device__ __forceinline__ f3 bxdf_value(const DevScene& sc, int mat, f3 Vi, f3 Vr, float2 uv) {
     const DevMaterial m = gld_rec<DevMaterial>(sc.materials, mat * (uint32_t)sizeof(DevMaterial));
     if (m.kind != RGK_BXDF_MIX) return bxdf_value_leaf(sc, m, Vi, Vr, uv);
     // s1*amt1 + s2*(1-amt1) with one nested level on either side
@@ -462,7 +462,7 @@ __device__ inline f3 bxdf_value(const DevScene& sc, int mat, f3 Vi, f3 Vr, float
 }
 
 // BxDF::sample, reference src/bxdf/bxdf.cpp:197-204,241-249,272-276,378-408,419-423, bxdf.hpp:115-159
-__device__ inline void bxdf_sample(const DevScene& sc, int mat, f3 Vi, float2 uv, float2 u, f3& dir, f3& weight, bool& may_leak) {
+__device__ __forceinline__ void bxdf_sample(const DevScene& sc, int mat, f3 Vi, float2 uv, float2 u, f3& dir, f3& weight, bool& may_leak) {
     DevMaterial m = gld_rec<DevMaterial>(sc.materials, mat * (uint32_t)sizeof(DevMaterial));
     for (int lvl = 0; lvl < 8 && m.kind == RGK_BXDF_MIX; lvl++) // BxDFMix::sample descends one side
         m = gld_rec<DevMaterial>(sc.materials, (uint32_t)(decide_and_rescale(u.x, m.amount) ? m.mix_m1 : m.mix_m2) * (uint32_t)sizeof(DevMaterial));
@@ -526,14 +526,14 @@ __device__ inline void bxdf_sample(const DevScene& sc, int mat, f3 Vi, float2 uv
     }
 }
 
-// The generic BxDF route (mirror, dielectric, transparent, mix) reads the scene through the device-resident copy
-// DevScene::self, and every function that takes the scene is force-inlined, so a kernel's by-value DevScene never
-// needs an address: its pointers stay in SGPRs instead of being copied to scratch at kernel entry and re-read from
-// there (which is what ONE out-of-line `const DevScene&` call used to cost).
+// Every function that takes the scene is force-inlined -- the generic BxDF route (mirror, dielectric, transparent,
+// mix) included -- so a kernel's by-value DevScene never needs an address: its pointers stay in SGPRs instead of being
+// copied to scratch at kernel entry and re-read from there (which is what ONE out-of-line `const DevScene&` call
+// used to cost).  (DevScene::self, a device-resident copy of the record, is kept for an out-of-line variant.)
 #define RGK_SLOW_ATTR __forceinline__ // measured: as an out-of-line call it costs the shade kernel 25 % (190 vs 153 ms per two rounds)
-__device__ RGK_SLOW_ATTR f3 bxdf_value_slow(const DevScene* gsc, int mat, f3 Vi, f3 Vr, float2 uv) { return bxdf_value(*gsc, mat, Vi, Vr, uv); }
-__device__ RGK_SLOW_ATTR void bxdf_sample_slow(const DevScene* gsc, int mat, f3 Vi, float2 uv, float2 u, f3& dir, f3& weight, bool& may_leak) {
-    bxdf_sample(*gsc, mat, Vi, uv, u, dir, weight, may_leak);
+__device__ RGK_SLOW_ATTR f3 bxdf_value_slow(const DevScene& sc, int mat, f3 Vi, f3 Vr, float2 uv) { return bxdf_value(sc, mat, Vi, Vr, uv); }
+__device__ RGK_SLOW_ATTR void bxdf_sample_slow(const DevScene& sc, int mat, f3 Vi, float2 uv, float2 u, f3& dir, f3& weight, bool& may_leak) {
+    bxdf_sample(sc, mat, Vi, uv, u, dir, weight, may_leak);
 }
 
 // Per-vertex material evaluation with everything `sample` and `value` share fetched once:
@@ -567,7 +567,7 @@ __device__ __forceinline__ void mat_prepare(const DevScene& sc, const DevMateria
 template <bool GENERIC = true>
 __device__ __forceinline__ void mat_sample(const DevScene& sc, int mat, const DevMaterial& m, const MatPrep& e, f3 VrL, float2 uv, float2 u,
                                   f3& dir, f3& weight, bool& may_leak) {
-    if (GENERIC && !e.fast) { bxdf_sample_slow(sc.self, mat, VrL, uv, u, dir, weight, may_leak); return; }
+    if (GENERIC && !e.fast) { bxdf_sample_slow(sc, mat, VrL, uv, u, dir, weight, may_leak); return; }
     may_leak = false;
     const f3 zero = mk3(0.f, 0.f, 0.f);
     bool lobe = m.kind != RGK_BXDF_DIFFUSE; // LTC lobe, unless the diffuse branch is chosen below
@@ -588,7 +588,7 @@ __device__ __forceinline__ void mat_sample(const DevScene& sc, int mat, const De
 }
 template <bool GENERIC = true>
 __device__ __forceinline__ f3 mat_value(const DevScene& sc, int mat, const DevMaterial& m, const MatPrep& e, f3 ViL, f3 VrL, float2 uv) {
-    if (GENERIC && !e.fast) return bxdf_value_slow(sc.self, mat, ViL, VrL, uv);
+    if (GENERIC && !e.fast) return bxdf_value_slow(sc, mat, ViL, VrL, uv);
     if (ViL.z <= 0 || VrL.z <= 0) return mk3(0.f, 0.f, 0.f);
     if (m.kind == RGK_BXDF_DIFFUSE) return e.diffc / RGK_PI_F;
     float pdf = ltc_pdf_M(e.Mv, ViL, VrL);
