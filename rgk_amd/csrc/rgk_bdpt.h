@@ -178,7 +178,7 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade_light(const DevSce
                     }
                     {
                         const f3 direction = norm3(v.pos - campos);
-                        f3 q = light_here * bxdf_value_slow(sc, (int)v.mat_id, v.VrL, qrot(v.g2l, -direction), v.uv);
+                        f3 q = light_here * mat_value_at(sc, (int)v.mat_id, v.mat, mp, v.VrL, qrot(v.g2l, -direction), v.uv);
                         const f3 dd = v.pos - campos;
                         const float G = fmaxf(0.0f, dot3(v.lightN, -direction)) / dot3(dd, dd);
                         int x2, y2;
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade_bdpt(const DevScen
                         const f3 p_to_light = -light_to_p;
                         const quatf lg2l = rotation_between(lN, mk3(0.f, 0.f, 1.f));
                         const f3 f_light = bxdf_value_slow(sc, (int)__float_as_uint(l0.w), qrot(lg2l, light_to_p), qrot(lg2l, lVr), luv);
-                        const f3 f_point = bxdf_value_slow(sc, (int)v.mat_id, v.VrL, qrot(v.g2l, p_to_light), v.uv);
+                        const f3 f_point = mat_value_at(sc, (int)v.mat_id, v.mat, mp, v.VrL, qrot(v.g2l, p_to_light), v.uv);
                         const f3 dd = v.pos - lpos;
                         const float G = fabsf(dot3(v.lightN, p_to_light)) / dot3(dd, dd);
                         rad = mk3(l3.x, l3.y, l3.z) * (f_light * f_point * G);

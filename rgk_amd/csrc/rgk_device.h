@@ -596,6 +596,20 @@ __device__ __forceinline__ f3 mat_value(const DevScene& sc, int mat, const DevMa
     return e.colorc * pdf;
 }
 
+// bxdf_value(mat, Vi, Vr) for ANY pair of directions at a vertex whose MatPrep exists (the bidirectional connections
+// evaluate the vertex's material once per light vertex, path_tracer.cpp:463-480): the texture colours fetched for
+// the vertex are reused, only the LTC entry -- interpolated at angle(Vr, N) -- is looked up again.  Same values as
+// bxdf_value_leaf; materials on the generic route go there.
+__device__ __forceinline__ f3 mat_value_at(const DevScene& sc, int mat, const DevMaterial& m, const MatPrep& e, f3 Vi, f3 Vr, float2 uv) {
+    if (!e.fast) return bxdf_value_slow(sc, mat, Vi, Vr, uv);
+    if (Vi.z <= 0 || Vr.z <= 0) return mk3(0.f, 0.f, 0.f);
+    if (m.kind == RGK_BXDF_DIFFUSE) return e.diffc / RGK_PI_F;
+    const uint32_t tab = (m.kind == RGK_BXDF_LTC_GGX || m.kind == RGK_BXDF_LTC_GGX_DIFFUSE) ? 0u : RGK_LTC_TABLE_BYTES;
+    const float pdf = ltc_pdf(sc.ltc, tab, Vi, Vr, m.roughness);
+    if (m.kind >= RGK_BXDF_LTC_BECKMANN_DIFFUSE) return e.colorc * pdf + e.diffc / RGK_PI_F;
+    return e.colorc * pdf;
+}
+
 // ------------------------------------------------------------------ lights / sky (a10, a15)
 struct DLight {
     f3 pos, color, normal;
