@@ -98,14 +98,15 @@ struct Step {
     bool go;
     f3 cum, no, nd;
 };
-__device__ inline void path_step(const DevScene& sc, const SamplerTab& tb, const Vertex& v, const MatPrep& mp, uint32_t seed, uint32_t s,
+template <bool GENERIC>
+__device__ __forceinline__ void path_step(const DevScene& sc, const SamplerTab& tb, const Vertex& v, const MatPrep& mp, uint32_t seed, uint32_t s,
                                  uint32_t dim2d, uint32_t n, uint32_t depth, float russian, f3 cum, uint32_t& c1, Step& st) {
     st.go = false; st.cum = cum; st.no = st.nd = mk3(0.f, 0.f, 0.f);
     if (!(n < depth)) return; // last vertex: nothing sampled here can be observed
     const quatf l2g = qinverse(v.g2l);
     float2 u = sample2d_t(tb, seed, s, dim2d);
     f3 dirL, weight; bool may_leak;
-    mat_sample(sc, (int)v.mat_id, v.mat, mp, v.VrL, v.uv, u, dirL, weight, may_leak);
+    mat_sample<GENERIC>(sc, (int)v.mat_id, v.mat, mp, v.VrL, v.uv, u, dirL, weight, may_leak);
     const bool inside = dirL.z < 0;
     const f3 dir = qrot(l2g, dirL);
     uint32_t n_eff = n;
@@ -129,23 +130,27 @@ __device__ inline void path_step(const DevScene& sc, const SamplerTab& tb, const
     st.go = go;
 }
 
+// GENERIC = false / true: as in k_shade -- the first launch shades every vertex whose materials all take the fast BxDF
+// route and lists the others (queue indices in pp.generic), the second walks that list with the full BxDF code.
 // ---- light sub-path vertex k: store it, splat it to the camera, continue (russian = -1: no roulette)
+template <bool GENERIC>
 __global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade_light(const DevScene sc, const DevCamera cam, const PassParams pp, const uint32_t k,
                                                                      const float4* __restrict__ rayA, const float4* __restrict__ rayB,
                                                                      const float4* __restrict__ hit, float4* __restrict__ thr,
                                                                      float4* __restrict__ nextA, float4* __restrict__ nextB, float4* __restrict__ shA,
                                                                      float4* __restrict__ shB, float4* __restrict__ shC, uint32_t* __restrict__ counters) {
-    const uint32_t count = counters[RGK_CNT_QUEUE + k];
+    const uint32_t count = counters[(GENERIC ? RGK_CNT_GENERIC : RGK_CNT_QUEUE) + k];
     const float eps = sc.epsilon;
     const SamplerTab tb = {pp.htab, pp.multisample};
     __shared__ uint32_t s_cnt[RGK_SHADE_BLOCK / 64];
     __shared__ uint32_t s_base;
     lut_lds_fill(sc);
     for (uint32_t base = blockIdx.x * RGK_SHADE_BLOCK; base < count; base += gridDim.x * RGK_SHADE_BLOCK) {
-        const uint32_t i = base + threadIdx.x;
-        bool cont = false, splat = false;
+        const bool valid = base + threadIdx.x < count;
+        const uint32_t i = !valid ? 0u : (GENERIC ? pp.generic[base + threadIdx.x] : base + threadIdx.x);
+        bool cont = false, splat = false, defer = false;
         float4 nA = make_float4(0, 0, 0, 0), nB = nA, sA = nA, sB = nA, sC = nA;
-        if (i < count) {
+        if (valid) {
             const float4 a = rayA[i], b = rayB[i], h = hit[i];
             const uint32_t slot = __float_as_uint(b.w);
             const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
@@ -156,7 +161,8 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade_light(const DevSce
             if (__float_as_int(h.w) >= 0) {
                 Vertex v;
                 surface_point(sc, pp.bumpmap_scale, o, d, h, v);
-                if (v.ok) {
+                defer = !GENERIC && v.ok && !mat_is_fast(v.mat.kind);
+                if (v.ok && !defer) {
                     const uint32_t srel = slot / pp.npix, j = slot - srel * pp.npix;
                     const uint32_t seed = pp.pix_seed[pp.j0 + j], s = pp.s0 + srel;
                     const uint32_t base2d = (cam.lens_size != 0.0f) ? 2u : 1u;
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade_light(const DevSce
                     }
                     {
                         const f3 direction = norm3(v.pos - campos);
-                        f3 q = light_here * mat_value_at(sc, (int)v.mat_id, v.mat, mp, v.VrL, qrot(v.g2l, -direction), v.uv);
+                        f3 q = light_here * mat_value_at<GENERIC>(sc, (int)v.mat_id, v.mat, mp, v.VrL, qrot(v.g2l, -direction), v.uv);
                         const f3 dd = v.pos - campos;
                         const float G = fmaxf(0.0f, dot3(v.lightN, -direction)) / dot3(dd, dd);
                         int x2, y2;
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade_light(const DevSce
                         }
                     }
                     Step st;
-                    path_step(sc, tb, v, mp, seed, s, base2d + 3u + pp.depth + (n - 1u), n, pp.reverse, -1.0f, cum, c1, st);
+                    path_step<GENERIC>(sc, tb, v, mp, seed, s, base2d + 3u + pp.depth + (n - 1u), n, pp.reverse, -1.0f, cum, c1, st);
                     if (st.go) {
                         cont = true;
                         nA = make_float4(st.no.x, st.no.y, st.no.z, st.nd.x);
@@ -207,31 +213,37 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade_light(const DevSce
         if (cont) { nextA[pn] = nA; nextB[pn] = nB; }
         const uint32_t ps = block_append(splat, &counters[RGK_CNT_SHADOW + k], s_cnt, &s_base);
         if (splat) { shA[ps] = sA; shB[ps] = sB; shC[ps] = sC; }
+        if (!GENERIC) {
+            const uint32_t pd = block_append(defer, &counters[RGK_CNT_GENERIC + k], s_cnt, &s_base);
+            if (defer) pp.generic[pd] = i;
+        }
     }
 }
 
 // ---- camera-path vertex with connections
+template <bool GENERIC>
 __global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade_bdpt(const DevScene sc, const DevCamera cam, const PassParams pp, const uint32_t bounce,
                                                                     const float4* __restrict__ rayA, const float4* __restrict__ rayB,
                                                                     const float4* __restrict__ hit, float4* __restrict__ thr, float4* __restrict__ tot,
                                                                     float4* __restrict__ nextA, float4* __restrict__ nextB, float4* __restrict__ shA,
                                                                     float4* __restrict__ shB, float4* __restrict__ shC, uint32_t* __restrict__ counters) {
-    const uint32_t count = counters[RGK_CNT_QUEUE + bounce];
+    const uint32_t count = counters[(GENERIC ? RGK_CNT_GENERIC : RGK_CNT_QUEUE) + bounce];
     const float eps = sc.epsilon;
     const SamplerTab tb = {pp.htab, pp.multisample};
     __shared__ uint32_t s_cnt[RGK_SHADE_BLOCK / 64];
     __shared__ uint32_t s_base;
     lut_lds_fill(sc);
     for (uint32_t base = blockIdx.x * RGK_SHADE_BLOCK; base < count; base += gridDim.x * RGK_SHADE_BLOCK) {
-        const uint32_t i = base + threadIdx.x;
-        bool cont = false, have = false;
+        const bool valid = base + threadIdx.x < count;
+        const uint32_t i = !valid ? 0u : (GENERIC ? pp.generic[base + threadIdx.x] : base + threadIdx.x);
+        bool cont = false, have = false, defer = false;
         float4 nA = make_float4(0, 0, 0, 0), nB = nA;
         Vertex v;
         v.ok = false;
         uint32_t slot = 0;
         MatPrep mp;
         mp.fast = false;
-        if (i < count) {
+        if (valid) {
             const float4 a = rayA[i], b = rayB[i], h = hit[i];
             slot = __float_as_uint(b.w);
             const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
@@ -247,7 +259,12 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade_bdpt(const DevScen
                 tot[slot] = t;
             } else {
                 surface_point(sc, pp.bumpmap_scale, o, d, h, v);
-                if (v.ok) {
+                if (!GENERIC && v.ok) { // every material this vertex will evaluate: its own and those of the path's light vertices
+                    defer = !mat_is_fast(v.mat.kind);
+                    for (uint32_t q = 0; q < pp.reverse; q++)
+                        if (lv_ptr(pp, q, 3, slot)->w != 0.0f && !mat_is_fast(mat_load(sc, __float_as_uint(lv_ptr(pp, q, 0, slot)->w)).kind)) defer = true;
+                }
+                if (v.ok && !defer) {
                     have = true;
                     const uint32_t srel = slot / pp.npix, j = slot - srel * pp.npix;
                     const uint32_t seed = pp.pix_seed[pp.j0 + j], s = pp.s0 + srel;
@@ -258,7 +275,7 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade_bdpt(const DevScen
                     pp.vfin[slot] = make_float4(cum.x, cum.y, cum.z, 1.0f); // contribution of this vertex
                     pp.vemit[slot] = make_float4(e_front.x, e_front.y, e_front.z, 0.f);
                     Step st;
-                    path_step(sc, tb, v, mp, seed, s, base2d + 3u + (n - 1u), n, pp.depth, pp.russian, cum, c1, st);
+                    path_step<GENERIC>(sc, tb, v, mp, seed, s, base2d + 3u + (n - 1u), n, pp.depth, pp.russian, cum, c1, st);
                     if (st.go) {
                         cont = true;
                         nA = make_float4(st.no.x, st.no.y, st.no.z, st.nd.x);
@@ -270,6 +287,10 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade_bdpt(const DevScen
         }
         const uint32_t pn = block_append(cont, &counters[RGK_CNT_QUEUE + bounce + 1], s_cnt, &s_base);
         if (cont) { nextA[pn] = nA; nextB[pn] = nB; }
+        if (!GENERIC) {
+            const uint32_t pd = block_append(defer, &counters[RGK_CNT_GENERIC + bounce], s_cnt, &s_base);
+            if (defer) pp.generic[pd] = i;
+        }
         // ---- q = 0: NEE to the path's light (:427-460); q = 1..reverse: light vertex q-1 (:463-480)
         for (uint32_t q = 0; q <= pp.reverse; q++) {
             bool shadow = false;
@@ -285,7 +306,7 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade_bdpt(const DevScen
                         from = L.pos;
                         const f3 dd = v.pos - L.pos;
                         const f3 Vi = norm3(L.pos - v.pos);
-                        const f3 f = mat_value(sc, (int)v.mat_id, v.mat, mp, qrot(v.g2l, Vi), v.VrL, v.uv);
+                        const f3 f = mat_value<GENERIC>(sc, (int)v.mat_id, v.mat, mp, qrot(v.g2l, Vi), v.VrL, v.uv);
                         const float G = fabsf(dot3(v.lightN, Vi)) / dot3(dd, dd);
                         const float kk = L.intensity * light_dir_factor(L, -Vi);
                         rad = (L.color * mk3(kk, kk, kk)) * (f * G);
@@ -301,8 +322,9 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade_bdpt(const DevScen
                         const f3 light_to_p = norm3(v.pos - lpos);
                         const f3 p_to_light = -light_to_p;
                         const quatf lg2l = rotation_between(lN, mk3(0.f, 0.f, 1.f));
-                        const f3 f_light = bxdf_value_slow(sc, (int)__float_as_uint(l0.w), qrot(lg2l, light_to_p), qrot(lg2l, lVr), luv);
-                        const f3 f_point = mat_value_at(sc, (int)v.mat_id, v.mat, mp, v.VrL, qrot(v.g2l, p_to_light), v.uv);
+                        const f3 f_light = GENERIC ? bxdf_value_slow(sc, (int)__float_as_uint(l0.w), qrot(lg2l, light_to_p), qrot(lg2l, lVr), luv)
+                                                   : bxdf_value_fastkind(sc, mat_load(sc, __float_as_uint(l0.w)), qrot(lg2l, light_to_p), qrot(lg2l, lVr), luv);
+                        const f3 f_point = mat_value_at<GENERIC>(sc, (int)v.mat_id, v.mat, mp, v.VrL, qrot(v.g2l, p_to_light), v.uv);
                         const f3 dd = v.pos - lpos;
                         const float G = fabsf(dot3(v.lightN, p_to_light)) / dot3(dd, dd);
                         rad = mk3(l3.x, l3.y, l3.z) * (f_light * f_point * G);

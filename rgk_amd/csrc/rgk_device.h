@@ -600,14 +600,29 @@ __device__ __forceinline__ f3 mat_value(const DevScene& sc, int mat, const DevMa
 // evaluate the vertex's material once per light vertex, path_tracer.cpp:463-480): the texture colours fetched for
 // the vertex are reused, only the LTC entry -- interpolated at angle(Vr, N) -- is looked up again.  Same values as
 // bxdf_value_leaf; materials on the generic route go there.
+template <bool GENERIC = true>
 __device__ __forceinline__ f3 mat_value_at(const DevScene& sc, int mat, const DevMaterial& m, const MatPrep& e, f3 Vi, f3 Vr, float2 uv) {
-    if (!e.fast) return bxdf_value_slow(sc, mat, Vi, Vr, uv);
+    if (GENERIC && !e.fast) return bxdf_value_slow(sc, mat, Vi, Vr, uv);
     if (Vi.z <= 0 || Vr.z <= 0) return mk3(0.f, 0.f, 0.f);
     if (m.kind == RGK_BXDF_DIFFUSE) return e.diffc / RGK_PI_F;
     const uint32_t tab = (m.kind == RGK_BXDF_LTC_GGX || m.kind == RGK_BXDF_LTC_GGX_DIFFUSE) ? 0u : RGK_LTC_TABLE_BYTES;
     const float pdf = ltc_pdf(sc.ltc, tab, Vi, Vr, m.roughness);
     if (m.kind >= RGK_BXDF_LTC_BECKMANN_DIFFUSE) return e.colorc * pdf + e.diffc / RGK_PI_F;
     return e.colorc * pdf;
+}
+
+// bxdf_value of a material KNOWN to take the fast route (diffuse, LTC) and of which nothing has been fetched yet
+// (the light vertex of a bidirectional connection): bxdf_value_leaf's cases for those kinds, nothing else compiled in.
+__device__ __forceinline__ f3 bxdf_value_fastkind(const DevScene& sc, const DevMaterial& m, f3 Vi, f3 Vr, float2 uv) {
+    if (Vi.z <= 0 || Vr.z <= 0) return mk3(0.f, 0.f, 0.f);
+    if (m.kind == RGK_BXDF_DIFFUSE) return tex_get(sc, m.t_diffuse, uv) / RGK_PI_F;
+    const uint32_t tab = (m.kind == RGK_BXDF_LTC_GGX || m.kind == RGK_BXDF_LTC_GGX_DIFFUSE) ? 0u : RGK_LTC_TABLE_BYTES;
+    if (m.kind >= RGK_BXDF_LTC_BECKMANN_DIFFUSE) {
+        f3 diff = tex_get(sc, m.t_diffuse, uv);
+        f3 spec = tex_get(sc, m.t_color, uv);
+        return spec * ltc_pdf(sc.ltc, tab, Vi, Vr, m.roughness) + diff / RGK_PI_F;
+    }
+    return tex_get(sc, m.t_color, uv) * ltc_pdf(sc.ltc, tab, Vi, Vr, m.roughness);
 }
 
 // ------------------------------------------------------------------ lights / sky (a10, a15)

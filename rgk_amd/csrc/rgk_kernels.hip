@@ -443,12 +443,14 @@ void rgk_launch_raygen_camera(hipStream_t st, const DevScene& sc, const DevCamer
 void rgk_launch_shade_light(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t k, const float4* rayA,
                             const float4* rayB, const float4* hit, float4* thr, float4* nextA, float4* nextB, float4* shA, float4* shB,
                             float4* shC, uint32_t* counters) {
-    k_shade_light<<<256 * 4 * 512 / RGK_SHADE_BLOCK, RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, k, rayA, rayB, hit, thr, nextA, nextB, shA, shB, shC, counters);
+    k_shade_light<false><<<bounded_grid(256 * 4 * 512 / RGK_SHADE_BLOCK, g_bound, RGK_SHADE_BLOCK), RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, k, rayA, rayB, hit, thr, nextA, nextB, shA, shB, shC, counters);
+    k_shade_light<true><<<bounded_grid(256 * 2 * 512 / RGK_SHADE_BLOCK, g_bound, RGK_SHADE_BLOCK), RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, k, rayA, rayB, hit, thr, nextA, nextB, shA, shB, shC, counters);
 }
 void rgk_launch_shade_bdpt(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t bounce,
                            const float4* rayA, const float4* rayB, const float4* hit, float4* thr, float4* tot, float4* nextA, float4* nextB,
                            float4* shA, float4* shB, float4* shC, uint32_t* counters) {
-    k_shade_bdpt<<<bounded_grid(256 * 4 * 512 / RGK_SHADE_BLOCK, g_bound, RGK_SHADE_BLOCK), RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
+    k_shade_bdpt<false><<<bounded_grid(256 * 4 * 512 / RGK_SHADE_BLOCK, g_bound, RGK_SHADE_BLOCK), RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
+    k_shade_bdpt<true><<<bounded_grid(256 * 2 * 512 / RGK_SHADE_BLOCK, g_bound, RGK_SHADE_BLOCK), RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
 }
 void rgk_launch_finish_vertex(hipStream_t st, const PassParams& pp, uint32_t bounce, const float4* rayB, float4* tot, const uint32_t* counters) {
     k_finish_vertex<<<bounded_grid(256 * 8, g_bound, 256), 256, 0, st>>>(pp, bounce, rayB, tot, counters);
