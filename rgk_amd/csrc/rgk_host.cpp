@@ -859,13 +859,14 @@ static void make_camera(const rgk_camera* c, DevCamera& o) {
 }
 
 // Paths resident per pass.  The path state is sized for the machine, not for a cache: by default
-// 48 GB of the 288 GB HBM3E (measured on Sponza 1080p x 256 spp: 2^25 paths/pass 2235 Mpaths/s,
-// 2^27 2398, 2^28 2440 -- fewer, longer launches and shorter tails).  RGK_BATCH_PATHS overrides.
+// 96 GB of the 288 GB HBM3E (measured on Sponza 1080p x 256 spp: 2^25 paths/pass 2235 Mpaths/s, 2^27 2398,
+// 2^28 2440 -- fewer, longer launches and shorter tails; 48 -> 96 GB: +1.4 % there, +6 % on the bidirectional
+// configuration whose paths carry 3.5x the state).  RGK_WORKSPACE_GB / RGK_BATCH_PATHS override.
 static size_t batch_paths(uint32_t reverse) {
     if (const char* e = getenv("RGK_BATCH_PATHS")) return std::max<size_t>(1024, strtoull(e, nullptr, 10));
     const size_t per_path = 180 + (reverse ? 48 + 64 * (size_t)reverse + 16 * ((size_t)reverse + 1) + 48 * (size_t)reverse : 0);
     const char* g = getenv("RGK_WORKSPACE_GB");
-    const double gb = g ? atof(g) : 48.0;
+    const double gb = g ? atof(g) : 96.0;
     size_t b = (size_t)(gb * 1e9 / (double)per_path);
     return std::min<size_t>(std::max<size_t>(b, 1024), (size_t)1 << 30);
 }
