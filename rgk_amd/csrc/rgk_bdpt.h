@@ -34,7 +34,7 @@ __device__ __forceinline__ uint32_t block_append(bool flag, uint32_t* counter, u
 }
 
 __device__ __forceinline__ float4* lv_ptr(const PassParams& pp, uint32_t k, uint32_t c, uint32_t slot) {
-    return pp.lv + ((size_t)(k * 4u + c) * pp.batch + slot);
+    return pp.lv + ((size_t)(k * RGK_LV_FLOAT4 + c) * pp.batch + slot);
 }
 
 // ---- light ray, path_tracer.cpp:336-349,359-363
@@ -175,6 +175,9 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade_light(const DevSce
                     *lv_ptr(pp, k, 1, slot) = make_float4(v.lightN.x, v.lightN.y, v.lightN.z, v.uv.x);
                     *lv_ptr(pp, k, 2, slot) = make_float4(v.Vr.x, v.Vr.y, v.Vr.z, v.uv.y);
                     *lv_ptr(pp, k, 3, slot) = make_float4(light_here.x, light_here.y, light_here.z, 1.0f);
+                    // the vertex's texture colours: every camera vertex that connects to it would fetch them again
+                    *lv_ptr(pp, k, 4, slot) = make_float4(mp.diffc.x, mp.diffc.y, mp.diffc.z, 0.f);
+                    *lv_ptr(pp, k, 5, slot) = make_float4(mp.colorc.x, mp.colorc.y, mp.colorc.z, 0.f);
                     // phase 2: connect to the camera, :377-397.  camerapos = r.origin of this sample.
                     f3 campos = mk3(cam.origin[0], cam.origin[1], cam.origin[2]);
                     if (cam.lens_size != 0.0f) {
@@ -323,7 +326,8 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade_bdpt(const DevScen
                         const f3 p_to_light = -light_to_p;
                         const quatf lg2l = rotation_between(lN, mk3(0.f, 0.f, 1.f));
                         const f3 f_light = GENERIC ? bxdf_value_slow(sc, (int)__float_as_uint(l0.w), qrot(lg2l, light_to_p), qrot(lg2l, lVr), luv)
-                                                   : bxdf_value_fastkind(sc, mat_load(sc, __float_as_uint(l0.w)), qrot(lg2l, light_to_p), qrot(lg2l, lVr), luv);
+                                                   : bxdf_value_fastkind(sc, mat_load(sc, __float_as_uint(l0.w)), *lv_ptr(pp, q - 1, 4, slot), *lv_ptr(pp, q - 1, 5, slot),
+                                                                         qrot(lg2l, light_to_p), qrot(lg2l, lVr));
                         const f3 f_point = mat_value_at<GENERIC>(sc, (int)v.mat_id, v.mat, mp, v.VrL, qrot(v.g2l, p_to_light), v.uv);
                         const f3 dd = v.pos - lpos;
                         const float G = fabsf(dot3(v.lightN, p_to_light)) / dot3(dd, dd);

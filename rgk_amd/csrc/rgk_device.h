@@ -611,18 +611,15 @@ __device__ __forceinline__ f3 mat_value_at(const DevScene& sc, int mat, const De
     return e.colorc * pdf;
 }
 
-// bxdf_value of a material KNOWN to take the fast route (diffuse, LTC) and of which nothing has been fetched yet
-// (the light vertex of a bidirectional connection): bxdf_value_leaf's cases for those kinds, nothing else compiled in.
-__device__ __forceinline__ f3 bxdf_value_fastkind(const DevScene& sc, const DevMaterial& m, f3 Vi, f3 Vr, float2 uv) {
+// bxdf_value of a material KNOWN to take the fast route (diffuse, LTC) given the two texture colours at its uv (the
+// light vertex of a bidirectional connection stores them, rgk_bdpt.h): bxdf_value_leaf's cases for those kinds.
+__device__ __forceinline__ f3 bxdf_value_fastkind(const DevScene& sc, const DevMaterial& m, float4 diffc, float4 colorc, f3 Vi, f3 Vr) {
     if (Vi.z <= 0 || Vr.z <= 0) return mk3(0.f, 0.f, 0.f);
-    if (m.kind == RGK_BXDF_DIFFUSE) return tex_get(sc, m.t_diffuse, uv) / RGK_PI_F;
+    const f3 diff = mk3(diffc.x, diffc.y, diffc.z), spec = mk3(colorc.x, colorc.y, colorc.z);
+    if (m.kind == RGK_BXDF_DIFFUSE) return diff / RGK_PI_F;
     const uint32_t tab = (m.kind == RGK_BXDF_LTC_GGX || m.kind == RGK_BXDF_LTC_GGX_DIFFUSE) ? 0u : RGK_LTC_TABLE_BYTES;
-    if (m.kind >= RGK_BXDF_LTC_BECKMANN_DIFFUSE) {
-        f3 diff = tex_get(sc, m.t_diffuse, uv);
-        f3 spec = tex_get(sc, m.t_color, uv);
-        return spec * ltc_pdf(sc.ltc, tab, Vi, Vr, m.roughness) + diff / RGK_PI_F;
-    }
-    return tex_get(sc, m.t_color, uv) * ltc_pdf(sc.ltc, tab, Vi, Vr, m.roughness);
+    if (m.kind >= RGK_BXDF_LTC_BECKMANN_DIFFUSE) return spec * ltc_pdf(sc.ltc, tab, Vi, Vr, m.roughness) + diff / RGK_PI_F;
+    return spec * ltc_pdf(sc.ltc, tab, Vi, Vr, m.roughness);
 }
 
 // ------------------------------------------------------------------ lights / sky (a10, a15)

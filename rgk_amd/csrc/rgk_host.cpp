@@ -413,7 +413,7 @@ int ensure_workspace(rgk_scene* s, size_t paths, uint32_t reverse = 0) {
     if (!rc) rc = s->shC.alloc(paths * (reverse + 1));
     if (reverse) {
         if (!rc) rc = s->lstart.alloc(paths);
-        if (!rc) rc = s->lv.alloc(paths * 4 * reverse);
+        if (!rc) rc = s->lv.alloc(paths * RGK_LV_FLOAT4 * reverse);
         if (!rc) rc = s->term.alloc(paths * (reverse + 1));
         if (!rc) rc = s->vfin.alloc(paths);
         if (!rc) rc = s->vemit.alloc(paths);
@@ -864,7 +864,7 @@ static void make_camera(const rgk_camera* c, DevCamera& o) {
 // configuration whose paths carry 3.5x the state).  RGK_WORKSPACE_GB / RGK_BATCH_PATHS override.
 static size_t batch_paths(uint32_t reverse) {
     if (const char* e = getenv("RGK_BATCH_PATHS")) return std::max<size_t>(1024, strtoull(e, nullptr, 10));
-    const size_t per_path = 180 + (reverse ? 48 + 64 * (size_t)reverse + 16 * ((size_t)reverse + 1) + 48 * (size_t)reverse : 0);
+    const size_t per_path = 180 + (reverse ? 48 + 16 * RGK_LV_FLOAT4 * (size_t)reverse + 16 * ((size_t)reverse + 1) + 48 * (size_t)reverse : 0);
     const char* g = getenv("RGK_WORKSPACE_GB");
     const double gb = g ? atof(g) : (reverse ? 160.0 : 96.0); // bidirectional paths carry 3.5x the state: 765 -> 781 Mpaths/s
     size_t b = (size_t)(gb * 1e9 / (double)per_path);

@@ -13,6 +13,7 @@
 #define RGK_SHADE_BLOCK 512
 #endif
 #define RGK_MAX_DEPTH 62
+#define RGK_LV_FLOAT4 6 // float4 per stored light vertex: {pos,mat}{lightN,u}{Vr,v}{light_from_source,valid}{diffuse colour}{specular colour}
 
 // device counter block (uint32), zeroed per pass by k_init_counters
 #define RGK_CNT_QUEUE 0     // [b]  rays in bounce b's queue        (b = 0..depth)
@@ -40,7 +41,7 @@ struct PassParams {
     float4* light;            // per slot: the path's light {pos.xyz, code}, written by k_raygen
     // bidirectional state (reverse > 0), null otherwise; per slot with stride `batch`
     float4* lstart;           // light_at_path_start.rgb
-    float4* lv;               // light vertices: lv[(k*4 + c) * batch + slot], c: {pos,mat}{lightN,u}{Vr,v}{light_from_source,valid}
+    float4* lv;               // light vertices: lv[(k*RGK_LV_FLOAT4 + c) * batch + slot], c: see RGK_LV_FLOAT4
     float4* term;             // term[q * batch + slot]: q = 0 NEE, q = 1..reverse connections
     float4* vfin;             // {contribution.rgb, 1 if the slot has a vertex awaiting k_finish_vertex}
     float4* vemit;            // emission of that vertex if front-facing
