@@ -637,8 +637,10 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
     if (qb.max_stack + 1 > 256) return fail(RGK_ERR_UNSUPPORTED, "BVH needs %u traversal-stack entries (max 256)", qb.max_stack + 1);
     {
         const int need = (int)qb.max_stack + 1;
-        const char* e = std::getenv("RGK_STACK_OVF"); // force the overflow variant (tests)
-        const bool ovf = need > 64 || (e && e[0] == '1' && need > 32);
+        // deeper than 32 entries: 32 in LDS (5 workgroups per CU) + the rest per lane in global memory beats the whole stack in
+        // LDS at 3 or 2 workgroups per CU (1 M-triangle scene: trace 905 -> 843 ms, shadow 225 -> 206 ms); RGK_STACK_OVF=0 = all LDS
+        const char* e = std::getenv("RGK_STACK_OVF");
+        const bool ovf = need > 64 || (need > 32 && !(e && e[0] == '0'));
         s->tcfg.stack = ovf ? 256 : (need <= 32 ? 32 : (need <= 48 ? 48 : 64));
         s->tcfg.lds = ovf ? 32 : s->tcfg.stack;
         s->tcfg.ovf = nullptr;

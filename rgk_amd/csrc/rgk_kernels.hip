@@ -365,9 +365,9 @@ int rgk_trace_grid(int lds_entries) {
     if (per_cu < 1) per_cu = 1;
     return 256 * per_cu;
 }
-// (stack need, LDS entries) variants: 32/32, 48/48, 64/64 hold the whole stack in LDS (occupancy 5, 3, 2 workgroups
-// per CU); a tree that needs more than 64 entries keeps 32 in LDS and the rest per lane in global memory (256/32).
-// (64/32 instead of 48/48 on the 1 M-triangle dragon scene was measured: no gain, 1062 vs 1015 ms of shadow rays.)
+// (stack need, LDS entries) variants: 32/32 holds the whole stack in LDS (5 workgroups per CU); a tree that needs more
+// keeps 32 entries in LDS and the rest per lane in global memory (256/32, still 5 workgroups per CU) -- measured better
+// on the 1 M-triangle scene than 48/48 or 64/64 (3 or 2 workgroups per CU), which remain behind RGK_STACK_OVF=0.
 #define RGK_TRACE_DISPATCH(K, BOUND, ...)                                                                   \
     {                                                                                                \
         const int grid = bounded_grid(rgk_trace_grid(tc.lds), BOUND, RGK_TRACE_BLOCK);               \
