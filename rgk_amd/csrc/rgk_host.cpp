@@ -635,17 +635,16 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
     qb.out.reserve(nodes.size() / 2 + 1);
     if (qb.collapse(0, 0, 0) != 0) return fail(RGK_ERR_DEVICE, "internal: QBVH root is not node 0");
     if (qb.max_stack + 1 > 256) return fail(RGK_ERR_UNSUPPORTED, "BVH needs %u traversal-stack entries (max 256)", qb.max_stack + 1);
-    {
+    {   // traversal stack: 16 entries per lane in LDS + per-lane overflow in global memory (rgk_kernels.hip RGK_TRACE_DISPATCH)
         const int need = (int)qb.max_stack + 1;
-        // deeper than 32 entries: 32 in LDS (5 workgroups per CU) + the rest per lane in global memory beats the whole stack in
-        // LDS at 3 or 2 workgroups per CU (1 M-triangle scene: trace 905 -> 843 ms, shadow 225 -> 206 ms); RGK_STACK_OVF=0 = all LDS
         const char* e = std::getenv("RGK_STACK_OVF");
-        const bool ovf = need > 64 || (need > 32 && !(e && e[0] == '0'));
-        s->tcfg.stack = ovf ? 256 : (need <= 32 ? 32 : (need <= 48 ? 48 : 64));
-        s->tcfg.lds = ovf ? 32 : s->tcfg.stack;
+        const char* l = std::getenv("RGK_STACK_LDS");
+        if (e && e[0] == '0' && need <= 32) { s->tcfg.stack = 32; s->tcfg.lds = 32; }
+        else { s->tcfg.stack = 256; s->tcfg.lds = (l && std::atoi(l) == 32) ? 32 : 16; }
         s->tcfg.ovf = nullptr;
-        if (ovf) { // 32 LDS entries + the rest per lane in global memory
-            if ((rc = s->ovf.alloc((size_t)rgk_trace_grid(s->tcfg.lds) * RGK_TRACE_BLOCK * (size_t)(s->tcfg.stack - s->tcfg.lds)))) return rc;
+        if (s->tcfg.lds < s->tcfg.stack) {
+            const size_t per_lane = (size_t)std::max(need - s->tcfg.lds, 1);
+            if ((rc = s->ovf.alloc((size_t)rgk_trace_grid(s->tcfg.lds) * RGK_TRACE_BLOCK * per_lane))) return rc;
             s->tcfg.ovf = s->ovf.p;
         }
     }

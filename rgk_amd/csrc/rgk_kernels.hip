@@ -365,16 +365,18 @@ int rgk_trace_grid(int lds_entries) {
     if (per_cu < 1) per_cu = 1;
     return 256 * per_cu;
 }
-// (stack need, LDS entries) variants: 32/32 holds the whole stack in LDS (5 workgroups per CU); a tree that needs more
-// keeps 32 entries in LDS and the rest per lane in global memory (256/32, still 5 workgroups per CU) -- measured better
-// on the 1 M-triangle scene than 48/48 or 64/64 (3 or 2 workgroups per CU), which remain behind RGK_STACK_OVF=0.
-#define RGK_TRACE_DISPATCH(K, BOUND, ...)                                                                   \
+// (stack need, LDS entries) variants.  Default 256/16: 16 entries per lane in LDS, the rest -- reached only by the deep
+// part of a walk -- per lane in global memory.  That keeps 8 workgroups per CU resident whatever the tree depth
+// (occupancy was LDS-bound: 5 per CU with 32 entries, 3 with 48), and more waves are what the L1-latency-bound half
+// of the kernel wanted: Sponza trace launch 40.3 -> 33.8 ms, shadow 25 -> 20 ms per round (32 / 24 / 16 / 12 / 8
+// entries: 40.3 / 37.0 / 35.1 / 35.5 / 35.2 ms at 7 waves per SIMD; 16 entries at 8 waves: 34.2).
+// RGK_STACK_LDS=32 selects 256/32, RGK_STACK_OVF=0 the all-LDS 32/32 (shallow trees only).
+#define RGK_TRACE_DISPATCH(K, BOUND, ...)                                                            \
     {                                                                                                \
         const int grid = bounded_grid(rgk_trace_grid(tc.lds), BOUND, RGK_TRACE_BLOCK);               \
-        if (tc.stack <= 32) { if (count_stats) K<true, 32, 32><<<grid, RGK_TRACE_BLOCK, 0, st>>>(__VA_ARGS__); else K<false, 32, 32><<<grid, RGK_TRACE_BLOCK, 0, st>>>(__VA_ARGS__); } \
+        if (tc.stack <= 32 && tc.lds == 32) { if (count_stats) K<true, 32, 32><<<grid, RGK_TRACE_BLOCK, 0, st>>>(__VA_ARGS__); else K<false, 32, 32><<<grid, RGK_TRACE_BLOCK, 0, st>>>(__VA_ARGS__); } \
         else if (tc.lds == 32) { if (count_stats) K<true, 256, 32><<<grid, RGK_TRACE_BLOCK, 0, st>>>(__VA_ARGS__); else K<false, 256, 32><<<grid, RGK_TRACE_BLOCK, 0, st>>>(__VA_ARGS__); } \
-        else if (tc.lds == 48) { if (count_stats) K<true, 48, 48><<<grid, RGK_TRACE_BLOCK, 0, st>>>(__VA_ARGS__); else K<false, 48, 48><<<grid, RGK_TRACE_BLOCK, 0, st>>>(__VA_ARGS__); } \
-        else { if (count_stats) K<true, 64, 64><<<grid, RGK_TRACE_BLOCK, 0, st>>>(__VA_ARGS__); else K<false, 64, 64><<<grid, RGK_TRACE_BLOCK, 0, st>>>(__VA_ARGS__); } \
+        else { if (count_stats) K<true, 256, 16><<<grid, RGK_TRACE_BLOCK, 0, st>>>(__VA_ARGS__); else K<false, 256, 16><<<grid, RGK_TRACE_BLOCK, 0, st>>>(__VA_ARGS__); } \
     }
 
 void rgk_launch_init_counters(hipStream_t st, uint32_t* counters, uint32_t n0) { k_init_counters<<<1, 256, 0, st>>>(counters, n0); }

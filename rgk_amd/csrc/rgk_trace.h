@@ -25,6 +25,9 @@
 #include "rgk_kernels.h"
 
 #define STACK_SENTINEL 0x7fffffff
+#ifndef RGK_TRACE_WAVES
+#define RGK_TRACE_WAVES 8 // waves per SIMD the 16-LDS-entry traversal kernels are compiled for (64 VGPRs); the 32-entry ones are LDS-bound at 5
+#endif
 #ifndef RGK_REFILL_BELOW
 #define RGK_REFILL_BELOW 24 // refill a wave when at most this many lanes still hold a ray (swept 8..60 with the majority walk: 24 best)
 #endif
@@ -291,7 +294,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
 
 // ------------------------------------------------------------------ K2: closest hit
 template <bool COUNT, int STACK, int LDSN>
-__global__ __launch_bounds__(RGK_TRACE_BLOCK) void k_trace_closest(const DevScene sc, const float4* __restrict__ rayA,
+__global__ __launch_bounds__(RGK_TRACE_BLOCK, (LDSN <= 16 ? RGK_TRACE_WAVES : 5)) void k_trace_closest(const DevScene sc, const float4* __restrict__ rayA,
                                                                     const float4* __restrict__ rayB, const float2* __restrict__ nearfar,
                                                                     float4* __restrict__ hit, const uint32_t* __restrict__ count_ptr,
                                                                     uint32_t* __restrict__ fetch, unsigned long long* __restrict__ stats, int* __restrict__ ovf) {
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(RGK_TRACE_BLOCK) void k_trace_closest(const DevScen
 // ------------------------------------------------------------------ K5: shadow rays + accumulate
 // shA = (o.xyz, d.x)  shB = (d.y, d.z, far, slot)  shC = (radiance.rgb, near)
 template <bool COUNT, int STACK, int LDSN>
-__global__ __launch_bounds__(RGK_TRACE_BLOCK) void k_trace_shadow(const DevScene sc, const float4* __restrict__ shA,
+__global__ __launch_bounds__(RGK_TRACE_BLOCK, (LDSN <= 16 ? RGK_TRACE_WAVES : 5)) void k_trace_shadow(const DevScene sc, const float4* __restrict__ shA,
                                                                    const float4* __restrict__ shB, const float4* __restrict__ shC,
                                                                    float4* __restrict__ tot, uint8_t* __restrict__ vis_out,
                                                                    const int mode, float* __restrict__ splat_rgb,
