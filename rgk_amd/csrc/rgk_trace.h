@@ -12,7 +12,8 @@
 // rays of one 64-ray batch finish at very different times.  So a wave keeps a cursor into its
 // chunk of the ray queue and, whenever at most RGK_REFILL_BELOW of its lanes still hold a ray, hands the idle ones fresh rays
 // (ballot + prefix popcount); a lane that drains its stack stores its hit and goes idle.
-// The per-lane traversal stack lives in LDS as [entry][lane] (bank = lane: conflict-free).
+// The first LDSN entries of the per-lane traversal stack live in LDS as [entry][lane] (bank = lane: conflict-free), the
+// deeper ones per lane in global memory: with the whole stack in LDS the kernel was LDS-bound at 5 waves per SIMD.
 //
 // Counters after the refill (profiles/r01_trace_pmc.txt): VALU issue ~100 % of SIMD cycles AND the vector L1
 // ~90 % occupied (TA busy 67 % + 32 % pending-line stalls; L1 hit rate 93 %) -- the kernel is co-limited, which is
