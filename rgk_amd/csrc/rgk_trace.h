@@ -26,6 +26,9 @@
 #include "rgk_kernels.h"
 
 #define STACK_SENTINEL 0x7fffffff
+#ifndef RGK_CHUNK_MAX
+#define RGK_CHUNK_MAX 2048u
+#endif
 #ifndef RGK_TRACE_WAVES
 #define RGK_TRACE_WAVES 8 // waves per SIMD the 16-LDS-entry traversal kernels are compiled for (64 VGPRs); the 32-entry ones are LDS-bound at 5
 #endif
@@ -82,7 +85,7 @@ __device__ __forceinline__ bool clip_to_scene(const DevScene& sc, f3 o, f3 d, fl
 // the queue.
 __device__ __forceinline__ uint32_t fetch_chunk(uint32_t count, uint32_t nwaves) {
     uint32_t c = (count / (nwaves * 4u)) & ~63u;
-    return c < 64u ? 64u : (c > 2048u ? 2048u : c);
+    return c < 64u ? 64u : (c > RGK_CHUNK_MAX ? RGK_CHUNK_MAX : c);
 }
 
 __device__ __forceinline__ float cvt_ubyte(uint32_t w, int c) { return (float)((w >> (8 * c)) & 0xffu); }
