@@ -134,12 +134,20 @@ typedef struct rgk_scene_desc {
     const float *ltc_beckmann;
 } rgk_scene_desc;
 
-/* ---- Camera constructor arguments, src/camera.cpp:7 ---- */
+/* ---- Camera as RenderRound(const Camera&) receives it (src/render_driver.cpp:146): the public data members
+ *      of the reference's Camera, src/camera.hpp:27-41, under their own names (`lookat` is not read on the path).
+ *      A host that holds a Camera copies the members; a host that only has the constructor arguments
+ *      (ConfigJSON::GetCamera, src/config.cpp:332-370) calls rgk_camera_init below. ---- */
 typedef struct rgk_camera {
-    float pos[3], lookat[3], up[3];
-    float yview, xview;
+    float origin[3];
+    float direction[3];
+    float cameraup[3];
+    float cameraleft[3];
+    float viewscreen[3];
+    float viewscreen_x[3];
+    float viewscreen_y[3];
+    float lens_size;
     int32_t xsize, ysize;
-    float focus_plane, lens_size;
 } rgk_camera;
 
 typedef enum rgk_sampler_kind {
@@ -225,6 +233,11 @@ int rgk_generate_task_list(uint32_t tile_size, uint32_t xres, uint32_t yres, flo
                            float mid_y, uint32_t seedstart, uint32_t seedcount_base,
                            rgk_tile *tiles, uint32_t *n_tiles);
 
+/* Camera::Camera(pos, la, up, yview, xview, xsize, ysize, focus_plane, lens_size), src/camera.cpp:7-24: fills the
+ * derived members from the constructor arguments, in the reference's operation order (host only, no device needed). */
+int rgk_camera_init(rgk_camera *out, const float pos[3], const float lookat[3], const float up[3], float yview,
+                    float xview, int32_t xsize, int32_t ysize, float focus_plane, float lens_size);
+
 /* The per-task body of RenderRound for a list of tiles (render_driver.cpp:158-184):
  * accum_rgb[3*(y*xres+x)..] += sum over samples, accum_count[y*xres+x] += multisample.
  * Host buffers; blocking. */
@@ -238,6 +251,40 @@ int rgk_render_round_device(rgk_scene *scene, const rgk_camera *camera,
                             const rgk_params *params, const rgk_tile *tiles, uint32_t n_tiles,
                             float *d_accum_rgb, uint32_t *d_accum_count,
                             rgk_counters *counters);
+
+/* ---- the frame accumulator on the device: EXRTexture total_ob of RenderFrame (src/render_driver.cpp:199,
+ *      src/texture.hpp:83-118: `data` = sum of radiance per pixel, `count` = samples per pixel).  A host without HIP
+ *      headers keeps its frame here and hands rgk_accum_rgb / rgk_accum_count to rgk_render_round_device. ---- */
+typedef struct rgk_accum rgk_accum;
+int rgk_accum_create(uint32_t xres, uint32_t yres, int device, rgk_accum **out); /* zeroed */
+void rgk_accum_destroy(rgk_accum *acc);
+int rgk_accum_clear(rgk_accum *acc);
+float *rgk_accum_rgb(rgk_accum *acc);      /* DEVICE pointer, 3 * xres * yres floats */
+uint32_t *rgk_accum_count(rgk_accum *acc); /* DEVICE pointer, xres * yres */
+int rgk_accum_download(const rgk_accum *acc, float *rgb, uint32_t *count); /* to host buffers (either may be NULL) */
+int rgk_accum_upload(rgk_accum *acc, const float *rgb, const uint32_t *count);
+
+/* Raw-accumulator checkpoint (the reference cannot resume a frame): the accumulator with the two numbers
+ * that make the next round continue the sequence -- rounds done and the running task counter `seedcount`
+ * (src/render_driver.cpp:160,222).  Rendering k rounds, saving, loading and rendering m more gives the bits of k + m rounds. */
+int rgk_accum_save(const rgk_accum *acc, const char *path, uint32_t rounds_done, uint32_t seedcount);
+int rgk_accum_load(rgk_accum *acc, const char *path, uint32_t *rounds_done, uint32_t *seedcount);
+
+/* ---- multi-GPU: one process per GPU, tiles dealt round-robin, ONE exchange per round ---- */
+typedef struct rgk_comm rgk_comm;
+#define RGK_COMM_ID_BYTES 128
+/* Tile i of the centre-out list goes to rank i mod world_size (tiles keep their seeds: the image does not depend on
+ * the number of GPUs).  Call with out == NULL for the count. */
+int rgk_shard_tiles(const rgk_tile *tiles, uint32_t n_tiles, int rank, int world_size, rgk_tile *out, uint32_t *n_out);
+/* RCCL communicator over the node's xGMI links.  Rank 0 makes the id and hands its 128 bytes to the other ranks by the
+ * host's own means (a file, an environment variable, MPI, ...).  librccl is bound at run time: single-GPU hosts need none. */
+int rgk_comm_get_unique_id(uint8_t id[RGK_COMM_ID_BYTES]);
+int rgk_comm_create(const uint8_t id[RGK_COMM_ID_BYTES], int rank, int world_size, int device, rgk_comm **out);
+void rgk_comm_destroy(rgk_comm *comm);
+/* total_ob.Accumulate(output_buffer) under total_ob_mx (src/render_driver.cpp:177-182) across GPUs: in-place sum-reduce of
+ * the per-GPU DEVICE accumulators to `root` (d_accum_count may be NULL when the host derives counts analytically).
+ * Collective and blocking: every rank calls it once per round. */
+int rgk_accum_reduce(rgk_comm *comm, float *d_accum_rgb, uint32_t *d_accum_count, uint32_t xres, uint32_t yres, int root);
 
 /* Scene::FindIntersectKdOtherThan (src/scene_intersect.cpp:211-327) for n rays.
  * rays: 8 floats each {ox,oy,oz, dx,dy,dz, near, far}; ignore: triangle id or -1. */

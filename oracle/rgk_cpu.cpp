@@ -889,18 +889,39 @@ struct Camera {
     vec3 origin, lookat, direction, cameraup, cameraleft, viewscreen, viewscreen_x, viewscreen_y;
     float lens_size;
     int xsize, ysize;
-    Camera(const rgk_camera& c) {
-        origin = vec3(c.pos[0], c.pos[1], c.pos[2]);
-        lookat = vec3(c.lookat[0], c.lookat[1], c.lookat[2]);
-        cameraup = vec3(c.up[0], c.up[1], c.up[2]);
-        xsize = c.xsize; ysize = c.ysize;
-        lens_size = c.lens_size;
+    Camera() {}
+    // Camera::Camera, src/camera.cpp:7-24
+    Camera(vec3 pos, vec3 la, vec3 up, float yview, float xview, int xres, int yres, float focus_plane, float ls) {
+        origin = pos;
+        lookat = la;
+        cameraup = up;
+        xsize = xres; ysize = yres;
+        lens_size = ls;
         direction = normalize(lookat - origin);
         cameraleft = normalize(cross(cameraup, direction));
         cameraup = normalize(cross(cameraleft, direction));
-        viewscreen_x = -c.xview * cameraleft * c.focus_plane;
-        viewscreen_y = c.yview * cameraup * c.focus_plane;
-        viewscreen = origin + direction * c.focus_plane - 0.5f * viewscreen_y - 0.5f * viewscreen_x;
+        viewscreen_x = -xview * cameraleft * focus_plane;
+        viewscreen_y = yview * cameraup * focus_plane;
+        viewscreen = origin + direction * focus_plane - 0.5f * viewscreen_y - 0.5f * viewscreen_x;
+    }
+    // the members as they cross the seam (include/rgk.h rgk_camera = src/camera.hpp:27-41)
+    Camera(const rgk_camera& c) {
+        origin = vec3(c.origin[0], c.origin[1], c.origin[2]);
+        lookat = origin;
+        direction = vec3(c.direction[0], c.direction[1], c.direction[2]);
+        cameraup = vec3(c.cameraup[0], c.cameraup[1], c.cameraup[2]);
+        cameraleft = vec3(c.cameraleft[0], c.cameraleft[1], c.cameraleft[2]);
+        viewscreen = vec3(c.viewscreen[0], c.viewscreen[1], c.viewscreen[2]);
+        viewscreen_x = vec3(c.viewscreen_x[0], c.viewscreen_x[1], c.viewscreen_x[2]);
+        viewscreen_y = vec3(c.viewscreen_y[0], c.viewscreen_y[1], c.viewscreen_y[2]);
+        xsize = c.xsize; ysize = c.ysize;
+        lens_size = c.lens_size;
+    }
+    void store(rgk_camera& c) const {
+        const vec3* src[7] = {&origin, &direction, &cameraup, &cameraleft, &viewscreen, &viewscreen_x, &viewscreen_y};
+        float* dst[7] = {c.origin, c.direction, c.cameraup, c.cameraleft, c.viewscreen, c.viewscreen_x, c.viewscreen_y};
+        for (int i = 0; i < 7; i++) { dst[i][0] = src[i]->x; dst[i][1] = src[i]->y; dst[i][2] = src[i]->z; }
+        c.lens_size = lens_size; c.xsize = xsize; c.ysize = ysize;
     }
     bool IsSimple() const { return lens_size == 0.0f; }
     vec3 GetViewScreenPoint(float x, float y) const {
@@ -1578,6 +1599,13 @@ int orc_texture_sample(void* h, int tex, const float* uv, float* rgb, float* slo
     rgb[0] = c.r; rgb[1] = c.g; rgb[2] = c.b;
     *slope_right = tex < 0 ? 0 : s->textures[tex].GetSlopeRight(vec2(uv[0], uv[1]));
     *slope_bottom = tex < 0 ? 0 : s->textures[tex].GetSlopeBottom(vec2(uv[0], uv[1]));
+    return 0;
+}
+// Camera::Camera for unit tests (the oracle's own restatement of src/camera.cpp:7-24)
+int orc_camera_init(rgk_camera* out, const float* pos, const float* la, const float* up, float yview, float xview, int xsize, int ysize,
+                    float focus_plane, float lens_size) {
+    Camera c(vec3(pos[0], pos[1], pos[2]), vec3(la[0], la[1], la[2]), vec3(up[0], up[1], up[2]), yview, xview, xsize, ysize, focus_plane, lens_size);
+    c.store(*out);
     return 0;
 }
 // Camera::GetPixelRay for unit tests

@@ -62,9 +62,10 @@ class SceneDesc(C.Structure):
 
 
 class Camera(C.Structure):
-    _fields_ = [("pos", f3), ("lookat", f3), ("up", f3), ("yview", C.c_float), ("xview", C.c_float),
-                ("xsize", C.c_int32), ("ysize", C.c_int32),
-                ("focus_plane", C.c_float), ("lens_size", C.c_float)]
+    """rgk_camera: the public members of the reference's Camera (src/camera.hpp:27-41)."""
+    _fields_ = [("origin", f3), ("direction", f3), ("cameraup", f3), ("cameraleft", f3),
+                ("viewscreen", f3), ("viewscreen_x", f3), ("viewscreen_y", f3),
+                ("lens_size", C.c_float), ("xsize", C.c_int32), ("ysize", C.c_int32)]
 
 
 class Params(C.Structure):
@@ -106,9 +107,12 @@ class Hit(C.Structure):
 
 # every symbol include/rgk.h declares (tests check the .so exports all of them)
 EXPORTS = ["rgk_last_error", "rgk_device_count", "rgk_scene_create", "rgk_scene_destroy",
-           "rgk_scene_get_info", "rgk_generate_task_list", "rgk_render_round",
+           "rgk_scene_get_info", "rgk_generate_task_list", "rgk_camera_init", "rgk_render_round",
            "rgk_render_round_device", "rgk_trace_closest", "rgk_trace_visibility",
-           "rgk_sampler_eval", "rgk_output_normalize", "rgk_output_write_exr", "rgk_float_to_half"]
+           "rgk_sampler_eval", "rgk_output_normalize", "rgk_output_write_exr", "rgk_float_to_half",
+           "rgk_accum_create", "rgk_accum_destroy", "rgk_accum_clear", "rgk_accum_rgb", "rgk_accum_count",
+           "rgk_accum_download", "rgk_accum_upload", "rgk_accum_save", "rgk_accum_load",
+           "rgk_shard_tiles", "rgk_comm_get_unique_id", "rgk_comm_create", "rgk_comm_destroy", "rgk_accum_reduce"]
 
 _p = C.POINTER
 
@@ -122,6 +126,7 @@ def _bind(lib):
     lib.rgk_scene_get_info.argtypes = [C.c_void_p, _p(SceneInfo)]
     lib.rgk_generate_task_list.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float,
                                            C.c_uint32, C.c_uint32, _p(Tile), _p(C.c_uint32)]
+    lib.rgk_camera_init.argtypes = [_p(Camera), f3, f3, f3, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_float, C.c_float]
     lib.rgk_render_round.argtypes = [C.c_void_p, _p(Camera), _p(Params), _p(Tile), C.c_uint32,
                                      C.c_void_p, C.c_void_p, _p(Counters)]
     lib.rgk_render_round_device.argtypes = lib.rgk_render_round.argtypes
@@ -133,6 +138,24 @@ def _bind(lib):
                                      C.c_void_p]
     lib.rgk_output_normalize.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p, _p(C.c_float)]
     lib.rgk_output_write_exr.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    lib.rgk_accum_create.argtypes = [C.c_uint32, C.c_uint32, C.c_int, _p(C.c_void_p)]
+    lib.rgk_accum_destroy.argtypes = [C.c_void_p]
+    lib.rgk_accum_destroy.restype = None
+    lib.rgk_accum_clear.argtypes = [C.c_void_p]
+    lib.rgk_accum_rgb.argtypes = [C.c_void_p]
+    lib.rgk_accum_rgb.restype = C.c_void_p
+    lib.rgk_accum_count.argtypes = [C.c_void_p]
+    lib.rgk_accum_count.restype = C.c_void_p
+    lib.rgk_accum_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.rgk_accum_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.rgk_accum_save.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32]
+    lib.rgk_accum_load.argtypes = [C.c_void_p, C.c_char_p, _p(C.c_uint32), _p(C.c_uint32)]
+    lib.rgk_shard_tiles.argtypes = [_p(Tile), C.c_uint32, C.c_int, C.c_int, _p(Tile), _p(C.c_uint32)]
+    lib.rgk_comm_get_unique_id.argtypes = [C.c_void_p]
+    lib.rgk_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _p(C.c_void_p)]
+    lib.rgk_comm_destroy.argtypes = [C.c_void_p]
+    lib.rgk_comm_destroy.restype = None
+    lib.rgk_accum_reduce.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]
     lib.rgk_float_to_half.argtypes = [C.c_float]
     lib.rgk_float_to_half.restype = C.c_uint16
     return lib

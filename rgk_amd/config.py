@@ -6,6 +6,7 @@ defaults), :328-370 (GetCamera), :372-387 (InstallLights), :389-413 (InstallSky)
 src/jsonutils.cpp:21-120 (incl. the `key255` variants that divide by 255).
 JSON is parsed with `//` and `/* */` comments allowed (jsoncpp Reader behaviour).
 """
+import ctypes as C
 import json
 import math
 import os
@@ -229,14 +230,7 @@ class Config:
             R = glm_rotate(f32(rotation) * f32(2.0) * f32(math.pi), up)[:3, :3]
             p = (R @ p).astype(f32)
             pos = lookat - p
-        c = capi.Camera()
-        c.pos[:] = [float(x) for x in pos]
-        c.lookat[:] = [float(x) for x in lookat]
-        c.up[:] = [float(x) for x in up]
-        c.yview, c.xview = float(yview), float(xview)
-        c.xsize, c.ysize = self.xres, self.yres
-        c.focus_plane, c.lens_size = float(focus_plane), float(lens_size)
-        return c
+        return camera_from_args(pos, lookat, up, yview, xview, self.xres, self.yres, focus_plane, lens_size)
 
     def get_params(self, sampler=capi.SAMPLER_HALTON, flags=0):
         """The PathTracer constructor arguments RenderRound passes (render_driver.cpp:164-173)."""
@@ -374,13 +368,20 @@ def make_camera(pos, lookat, up=(0.0, 1.0, 0.0), fov=None, focal=None, xres=1, y
     else:
         xview = fov2xview(f32(fov))
         yview = f32(xview * f32(yres)) / f32(xres)
+    return camera_from_args(pos, lookat, up, yview, xview, xres, yres, focus_plane, lens_size)
+
+
+def camera_from_args(pos, lookat, up, yview, xview, xres, yres, focus_plane=1.0, lens_size=0.0):
+    """Camera::Camera (src/camera.cpp:7-24) through the C ABI (rgk_camera_init): the derived members that
+    RenderRound's `const Camera&` carries.  `.ctor` keeps the constructor arguments for fixtures and tests."""
     c = capi.Camera()
-    c.pos[:] = [float(f32(x)) for x in pos]
-    c.lookat[:] = [float(f32(x)) for x in lookat]
-    c.up[:] = [float(f32(x)) for x in up]
-    c.yview, c.xview = float(yview), float(xview)
-    c.xsize, c.ysize = xres, yres
-    c.focus_plane, c.lens_size = float(focus_plane), float(lens_size)
+    lib = capi.load_product()
+    args = dict(pos=[float(f32(x)) for x in pos], lookat=[float(f32(x)) for x in lookat], up=[float(f32(x)) for x in up],
+                yview=float(f32(yview)), xview=float(f32(xview)), xsize=int(xres), ysize=int(yres),
+                focus_plane=float(f32(focus_plane)), lens_size=float(f32(lens_size)))
+    capi.check(lib, lib.rgk_camera_init(C.byref(c), capi.f3(*args["pos"]), capi.f3(*args["lookat"]), capi.f3(*args["up"]), args["yview"],
+                                        args["xview"], args["xsize"], args["ysize"], args["focus_plane"], args["lens_size"]))
+    c.ctor = args
     return c
 
 

@@ -375,7 +375,7 @@ struct rgk_scene {
     uint32_t batch_reverse = 0;
     DevBuf<float> htab;
     DevBuf<float2> nearfar;
-    DevBuf<uint32_t> counters, pix_xy, pix_seed;
+    DevBuf<uint32_t> counters, pix_xy, pix_seed, tile_buf;
     DevBuf<unsigned long long> stats;
     DevBuf<float> scratch_f;
     DevBuf<uint32_t> scratch_u;
@@ -391,7 +391,7 @@ struct rgk_scene {
         for (int i = 0; i < 2; i++) { rayA[i].release(); rayB[i].release(); }
         hit.release(); thr.release(); tot.release(); shA.release(); shB.release(); shC.release(); pixsum.release();
         light.release(); generic.release(); htab.release(); lstart.release(); lv.release(); term.release(); vfin.release(); vemit.release();
-        nearfar.release(); counters.release(); pix_xy.release(); pix_seed.release(); stats.release();
+        nearfar.release(); counters.release(); pix_xy.release(); pix_seed.release(); tile_buf.release(); stats.release();
         scratch_f.release(); scratch_u.release();
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -401,8 +401,7 @@ namespace {
 
 int ensure_workspace(rgk_scene* s, size_t paths, uint32_t reverse = 0) {
     if (paths <= s->batch && reverse <= s->batch_reverse) return 0;
-    paths = std::max(paths, s->batch);
-    reverse = std::max(reverse, s->batch_reverse);
+    if (s->batch) { paths = std::max(paths, s->batch); reverse = std::max(reverse, s->batch_reverse); }
     int rc = 0;
     for (int i = 0; i < 2 && !rc; i++) { rc = s->rayA[i].alloc(paths); if (!rc) rc = s->rayB[i].alloc(paths); }
     if (!rc) rc = s->hit.alloc(paths);
@@ -422,7 +421,7 @@ int ensure_workspace(rgk_scene* s, size_t paths, uint32_t reverse = 0) {
     if (!rc) rc = s->generic.alloc(paths);
     if (!rc) rc = s->counters.alloc(2 * RGK_CNT_TOTAL); // [0]: camera phase, [1]: light sub-path phase
     if (!rc) rc = s->stats.alloc(8);
-    if (rc) return rc;
+    if (rc) { s->batch = 0; s->batch_reverse = 0; return rc; } // some buffers are gone: the next call starts over
     if (!s->h_counters) HIPCHK(hipHostMalloc((void**)&s->h_counters, 2 * RGK_CNT_TOTAL * sizeof(uint32_t)));
     s->batch = paths;
     s->batch_reverse = reverse;
@@ -494,6 +493,27 @@ int validate_desc(const rgk_scene_desc* d) {
             return fail(RGK_ERR_INVALID, "material %u: mix children out of range", i);
         if (m.kind == RGK_BXDF_LTC_GGX || m.kind == RGK_BXDF_LTC_GGX_DIFFUSE) ggx = true;
         if (m.kind == RGK_BXDF_LTC_BECKMANN || m.kind == RGK_BXDF_LTC_BECKMANN_DIFFUSE) bek = true;
+    }
+    {   // BxDFMix recurses (bxdf.cpp:235-249); the kernels evaluate a mix of mixes of leaves (two levels) without recursion.
+        // Anything deeper, or a mix that reaches itself, is refused here rather than rendered wrong.
+        std::vector<int> depth(d->n_materials, -1); // -1 unvisited, -2 on the current walk
+        struct Walk {
+            const rgk_scene_desc* d; std::vector<int>& depth;
+            int go(uint32_t i) {
+                if (d->materials[i].kind != RGK_BXDF_MIX) return depth[i] = 0;
+                if (depth[i] == -2) return -1; // cycle
+                if (depth[i] >= 0) return depth[i];
+                depth[i] = -2;
+                const int a = go((uint32_t)d->materials[i].mix_m1), b = go((uint32_t)d->materials[i].mix_m2);
+                if (a < 0 || b < 0) return -1;
+                return depth[i] = 1 + std::max(a, b);
+            }
+        } walk{d, depth};
+        for (uint32_t i = 0; i < d->n_materials; i++) {
+            const int k = walk.go(i);
+            if (k < 0) return fail(RGK_ERR_INVALID, "material %u: mix materials form a cycle", i);
+            if (k > 2) return fail(RGK_ERR_UNSUPPORTED, "material %u: mix nested %d levels deep (at most 2 are evaluated)", i, k);
+        }
     }
     if (ggx && !d->ltc_ggx) return fail(RGK_ERR_INVALID, "LTC GGX material without ltc_ggx table");
     if (bek && !d->ltc_beckmann) return fail(RGK_ERR_INVALID, "LTC Beckmann material without ltc_beckmann table");
@@ -842,20 +862,31 @@ int rgk_generate_task_list(uint32_t tile_size, uint32_t xres, uint32_t yres, flo
     return RGK_OK;
 }
 
-static void make_camera(const rgk_camera* c, DevCamera& o) {
+int rgk_camera_init(rgk_camera* o, const float pos[3], const float lookat[3], const float upv[3], float yview, float xview, int32_t xsize,
+                    int32_t ysize, float focus_plane, float lens_size) {
     // Camera::Camera, reference src/camera.cpp:7-24
-    V3 origin{c->pos[0], c->pos[1], c->pos[2]}, lookat{c->lookat[0], c->lookat[1], c->lookat[2]}, up{c->up[0], c->up[1], c->up[2]};
-    V3 direction = normv(sub(lookat, origin));
+    if (!o || !pos || !lookat || !upv) return fail(RGK_ERR_INVALID, "null argument");
+    V3 origin{pos[0], pos[1], pos[2]}, la{lookat[0], lookat[1], lookat[2]}, up{upv[0], upv[1], upv[2]};
+    V3 direction = normv(sub(la, origin));
     V3 left = normv(crossv(up, direction));
     up = normv(crossv(left, direction));
-    V3 vx = scale(scale(left, -c->xview), c->focus_plane);
-    V3 vy = scale(scale(up, c->yview), c->focus_plane);
-    V3 a = {origin.x + direction.x * c->focus_plane, origin.y + direction.y * c->focus_plane, origin.z + direction.z * c->focus_plane};
+    V3 vx = scale(scale(left, -xview), focus_plane);
+    V3 vy = scale(scale(up, yview), focus_plane);
+    V3 a = {origin.x + direction.x * focus_plane, origin.y + direction.y * focus_plane, origin.z + direction.z * focus_plane};
     V3 hy = scale(vy, 0.5f), hx = scale(vx, 0.5f);
     V3 vs = sub(sub(a, hy), hx);
     auto put = [](float* dst, V3 v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; };
-    put(o.origin, origin); put(o.direction, direction); put(o.up, up); put(o.left, left);
-    put(o.viewscreen, vs); put(o.viewscreen_x, vx); put(o.viewscreen_y, vy);
+    put(o->origin, origin); put(o->direction, direction); put(o->cameraup, up); put(o->cameraleft, left);
+    put(o->viewscreen, vs); put(o->viewscreen_x, vx); put(o->viewscreen_y, vy);
+    o->lens_size = lens_size; o->xsize = xsize; o->ysize = ysize;
+    return RGK_OK;
+}
+
+static void make_camera(const rgk_camera* c, DevCamera& o) { // the members RenderRound's `const Camera&` carries, as they are
+    for (int k = 0; k < 3; k++) {
+        o.origin[k] = c->origin[k]; o.direction[k] = c->direction[k]; o.up[k] = c->cameraup[k]; o.left[k] = c->cameraleft[k];
+        o.viewscreen[k] = c->viewscreen[k]; o.viewscreen_x[k] = c->viewscreen_x[k]; o.viewscreen_y[k] = c->viewscreen_y[k];
+    }
     o.lens_size = c->lens_size; o.xsize = c->xsize; o.ysize = c->ysize;
 }
 
@@ -867,7 +898,11 @@ static size_t batch_paths(uint32_t reverse) {
     if (const char* e = getenv("RGK_BATCH_PATHS")) return std::max<size_t>(1024, strtoull(e, nullptr, 10));
     const size_t per_path = 180 + (reverse ? 48 + 16 * RGK_LV_FLOAT4 * (size_t)reverse + 16 * ((size_t)reverse + 1) + 48 * (size_t)reverse : 0);
     const char* g = getenv("RGK_WORKSPACE_GB");
-    const double gb = g ? atof(g) : (reverse ? 160.0 : 96.0); // bidirectional paths carry 3.5x the state: 765 -> 781 Mpaths/s
+    double gb = g ? atof(g) : (reverse ? 160.0 : 96.0); // bidirectional paths carry 3.5x the state: 765 -> 781 Mpaths/s
+    if (!g) { // a shared or smaller card: never plan for more than 60 % of what is free right now
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) gb = std::min(gb, 0.6 * (double)free_b / 1e9);
+    }
     size_t b = (size_t)(gb * 1e9 / (double)per_path);
     return std::min<size_t>(std::max<size_t>(b, 1024), (size_t)1 << 30);
 }
@@ -882,37 +917,45 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
     if (prm->sampler != RGK_SAMPLER_HALTON) return fail(RGK_ERR_UNSUPPORTED, "the HIP path implements the Halton sampler only");
     HIPCHK(hipSetDevice(s->device));
     if (counters) std::memset(counters, 0, sizeof(*counters));
-    // ---- pixel list in Tracer::Render order, per-pixel seeds (a1, a2)
-    std::vector<uint32_t> pxy, pseed;
+    // ---- pixel list in Tracer::Render order, per-pixel seeds (a1, a2): built on the device from the tile list
+    std::vector<uint32_t> toff(n_tiles + 1, 0u);
     for (uint32_t i = 0; i < n_tiles; i++) {
         const rgk_tile& t = tiles[i];
         if (t.x1 > prm->xres || t.y1 > prm->yres || t.x0 > t.x1 || t.y0 > t.y1) return fail(RGK_ERR_INVALID, "tile %u outside the frame", i);
-        // The seed of a pixel is fixed by its row-major rank k inside the task (RenderPixel is called in
-        // that order, tracer.cpp:8-9, and bumps the seed first, path_tracer.cpp:47).  The ORDER in which
-        // pixels occupy path slots is free: 8x8 blocks, so the 64 lanes of a wave start as a compact
-        // bundle of camera rays instead of two 32-pixel row segments (coherent traversal and shading).
-        const uint32_t tw = t.x1 - t.x0, th = t.y1 - t.y0;
-        for (uint32_t by = 0; by < th; by += 8)
-            for (uint32_t bx = 0; bx < tw; bx += 8)
-                for (uint32_t y = by; y < std::min(by + 8, th); y++)
-                    for (uint32_t x = bx; x < std::min(bx + 8, tw); x++) {
-                        const uint32_t k = y * tw + x;
-                        pxy.push_back((t.x0 + x) | ((t.y0 + y) << 16));
-                        pseed.push_back(t.seed + (k + 1u) * 0x42424242u);
-                    }
+        const uint64_t n = (uint64_t)toff[i] + (uint64_t)(t.x1 - t.x0) * (t.y1 - t.y0);
+        if (n >= (1ull << 31)) return fail(RGK_ERR_UNSUPPORTED, "more than 2^31 pixels in one round");
+        toff[i + 1] = (uint32_t)n;
     }
-    const size_t P = pxy.size();
+    const size_t P = toff[n_tiles];
     if (P == 0) return RGK_OK;
     int rc;
-    if ((rc = s->pix_xy.upload(pxy)) || (rc = s->pix_seed.upload(pseed))) return rc;
+    {
+        hipStream_t st0 = s->stream;
+        if ((rc = s->pix_xy.alloc(P)) || (rc = s->pix_seed.alloc(P)) || (rc = s->tile_buf.alloc((size_t)n_tiles * 5 + n_tiles + 1))) return rc;
+        // (both sources outlive the copies: `toff` lives to the end of this call, which synchronises the stream before returning)
+        static_assert(sizeof(rgk_tile) == 5 * sizeof(uint32_t), "rgk_tile layout");
+        HIPCHK(hipMemcpyAsync(s->tile_buf.p, tiles, (size_t)n_tiles * sizeof(rgk_tile), hipMemcpyHostToDevice, st0));
+        HIPCHK(hipMemcpyAsync(s->tile_buf.p + (size_t)n_tiles * 5, toff.data(), (n_tiles + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st0));
+        rgk_launch_build_pixel_list(st0, reinterpret_cast<const rgk_tile*>(s->tile_buf.p), s->tile_buf.p + (size_t)n_tiles * 5, n_tiles, s->pix_xy.p, s->pix_seed.p);
+    }
     // no light at all: TracePath builds no light sub-path (`reverse > 0 && valid light`), same as reverse == 0
     const uint32_t R = (s->dev.total_point_power + s->dev.total_areal_power > 0.0f) ? prm->reverse : 0u;
-    const size_t B = batch_paths(R);
-    const size_t npix_pass = std::min(P, B);
-    const uint32_t ns_max = (uint32_t)std::max<size_t>(1, std::min<size_t>(prm->multisample, B / npix_pass));
-    const uint32_t n_sample_passes = (prm->multisample + ns_max - 1) / ns_max;
-    const uint32_t ns_pass = (prm->multisample + n_sample_passes - 1) / n_sample_passes; // equal-sized passes
-    if ((rc = ensure_workspace(s, npix_pass * ns_pass, R))) return rc;
+    // paths per pass: what the card has room for now (an existing workspace counts as room); halved on an allocation failure
+    size_t B = batch_paths(R);
+    if (s->batch_reverse >= R) B = std::max(B, s->batch);
+    size_t npix_pass;
+    uint32_t ns_pass;
+    for (;;) {
+        npix_pass = std::min(P, B);
+        const uint32_t ns_max = (uint32_t)std::max<size_t>(1, std::min<size_t>(prm->multisample, B / npix_pass));
+        const uint32_t n_sample_passes = (prm->multisample + ns_max - 1) / ns_max;
+        ns_pass = (prm->multisample + n_sample_passes - 1) / n_sample_passes; // equal-sized passes
+        rc = ensure_workspace(s, npix_pass * ns_pass, R);
+        if (rc != RGK_ERR_OOM || B <= ((size_t)1 << 20)) break;
+        (void)hipGetLastError();
+        B /= 2;
+    }
+    if (rc) return rc;
     if ((rc = s->pixsum.alloc(P))) return rc;
 
     DevCamera cam;
@@ -959,8 +1002,17 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
         volatile uint32_t* h = s->h_counters;
         h[0] = 0xffffffffu; // never a queue length (queues hold < 2^30 entries)
         HIPCHK(hipMemcpyAsync(s->h_counters, dptr, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        for (uint64_t spins = 0; h[0] == 0xffffffffu; spins++)
-            if ((spins & 0xfffff) == 0xfffff && hipStreamQuery(st) == hipSuccess && h[0] == 0xffffffffu) { HIPCHK(hipStreamSynchronize(st)); break; }
+        for (uint64_t spins = 0; h[0] == 0xffffffffu; spins++) {
+            if ((spins & 0xfffff) != 0xfffff) continue;
+            // every ~1 M polls ask the stream: not-ready means keep polling, success means the copy has landed (re-read), anything
+            // else is a sticky launch / device error that would otherwise spin here for ever
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipErrorNotReady) continue;
+            if (q != hipSuccess) return fail(RGK_ERR_DEVICE, "queue-length read-back: %s", hipGetErrorString(q));
+            if (h[0] == 0xffffffffu) HIPCHK(hipStreamSynchronize(st));
+            if (h[0] == 0xffffffffu) return fail(RGK_ERR_DEVICE, "queue-length read-back never landed");
+            break;
+        }
         out = h[0];
         return 0;
     };

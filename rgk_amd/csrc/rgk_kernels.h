@@ -50,6 +50,7 @@ struct PassParams {
 };
 
 void rgk_launch_init_counters(hipStream_t st, uint32_t* counters, uint32_t n0);
+void rgk_launch_build_pixel_list(hipStream_t st, const rgk_tile* tiles, const uint32_t* tile_off, uint32_t n_tiles, uint32_t* pix_xy, uint32_t* pix_seed);
 void rgk_launch_build_halton_table(hipStream_t st, const DevScene& sc, uint32_t S, float* htab);
 void rgk_launch_raygen(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, float4* rayA, float4* rayB,
                        float4* thr, float4* tot);

@@ -296,6 +296,35 @@ __global__ __launch_bounds__(256) void k_resolve(const PassParams pp, const floa
     }
 }
 
+// The round's pixel list in Tracer::Render order with the per-pixel seeds (a1, a2), built on the device from the tile list
+// (2040 tiles at 1080p: a few KB up instead of 16 MB of host-built lists every round).  The seed of a pixel is fixed by its
+// row-major rank k inside the task (RenderPixel is called in that order, tracer.cpp:8-9, and bumps the seed first,
+// path_tracer.cpp:47).  The ORDER in which pixels occupy path slots is free: 8x8 blocks, so the 64 lanes of a wave start as
+// a compact bundle of camera rays instead of two 32-pixel row segments (coherent traversal and shading).
+__global__ __launch_bounds__(256) void k_build_pixel_list(const rgk_tile* __restrict__ tiles, const uint32_t* __restrict__ tile_off, uint32_t n_tiles,
+                                                           uint32_t* __restrict__ pix_xy, uint32_t* __restrict__ pix_seed) {
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const rgk_tile tl = tiles[t];
+        const uint32_t tw = tl.x1 - tl.x0, th = tl.y1 - tl.y0, base = tile_off[t];
+        for (uint32_t q = threadIdx.x; q < tw * th; q += blockDim.x) {
+            // slot q of the tile in 8x8-block order -> (x, y) inside the tile
+            const uint32_t nbr = (th + 7u) >> 3, nbc = (tw + 7u) >> 3;
+            uint32_t r = q / (8u * tw);
+            if (r > nbr - 1u) r = nbr - 1u;
+            const uint32_t rem = q - r * 8u * tw;
+            const uint32_t bh = (th - 8u * r) < 8u ? (th - 8u * r) : 8u;
+            uint32_t c = rem / (bh * 8u);
+            if (c > nbc - 1u) c = nbc - 1u;
+            const uint32_t rem2 = rem - c * bh * 8u;
+            const uint32_t bw = (tw - 8u * c) < 8u ? (tw - 8u * c) : 8u;
+            const uint32_t y = 8u * r + rem2 / bw, x = 8u * c + rem2 % bw;
+            const uint32_t k = y * tw + x;
+            pix_xy[base + q] = (tl.x0 + x) | ((tl.y0 + y) << 16);
+            pix_seed[base + q] = tl.seed + (k + 1u) * 0x42424242u;
+        }
+    }
+}
+
 // halton_raw tabulated once per round: htab[hdim * S + s]
 __global__ void k_build_halton_table(const DevScene sc, uint32_t S, float* __restrict__ htab) {
     const uint32_t n = 192u * S;
@@ -380,6 +409,9 @@ int rgk_trace_grid(int lds_entries) {
     }
 
 void rgk_launch_init_counters(hipStream_t st, uint32_t* counters, uint32_t n0) { k_init_counters<<<1, 256, 0, st>>>(counters, n0); }
+void rgk_launch_build_pixel_list(hipStream_t st, const rgk_tile* tiles, const uint32_t* tile_off, uint32_t n_tiles, uint32_t* pix_xy, uint32_t* pix_seed) {
+    k_build_pixel_list<<<n_tiles < 4096u ? n_tiles : 4096u, 256, 0, st>>>(tiles, tile_off, n_tiles, pix_xy, pix_seed);
+}
 void rgk_launch_build_halton_table(hipStream_t st, const DevScene& sc, uint32_t S, float* htab) {
     uint32_t n = 192u * S;
     k_build_halton_table<<<(n + 255) / 256, 256, 0, st>>>(sc, S, htab);

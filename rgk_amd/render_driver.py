@@ -36,11 +36,12 @@ def generate_task_list(xres, yres, seedstart=SEEDSTART, seedcount_base=0, tile_s
 
 
 def shard_tiles(tiles, rank, world_size):
-    """Round-robin deal of the centre-out list: tile i -> rank i % world_size."""
-    idx = list(range(rank, len(tiles), world_size))
-    out = (capi.Tile * len(idx))()
-    for k, i in enumerate(idx):
-        out[k] = tiles[i]
+    """Round-robin deal of the centre-out list: tile i -> rank i % world_size (rgk_shard_tiles)."""
+    lib = capi.load_product()
+    n = C.c_uint32(0)
+    capi.check(lib, lib.rgk_shard_tiles(tiles, len(tiles), rank, world_size, None, C.byref(n)))
+    out = (capi.Tile * n.value)()
+    capi.check(lib, lib.rgk_shard_tiles(tiles, len(tiles), rank, world_size, out, C.byref(n)))
     return out
 
 
@@ -196,45 +197,94 @@ class RenderDriver:
         self.rounds_done = 0
         self.counters = []
         self.host_reduce = host_reduce  # gloo rehearsal: reduce through host copies instead of RCCL
+        self.round_ob = None
+        self.clock = time.time
 
     def render_round(self, reduce=True):
-        """One RenderRound: every rank renders its tiles into its private accumulator, then one
-        sum-reduce to rank 0 (no data-path collective inside the round)."""
+        """One RenderRound: every rank renders its tiles into its private accumulator, then ONE sum-reduce of the RGB
+        accumulator to rank 0 (no data-path collective inside the round).  Sample counts are not exchanged: every tile
+        list covers the frame and every pixel of it gains `multisample` samples per round, splats add none
+        (tracer.cpp:18,25), so rank 0 adds that constant itself."""
         import torch
         tiles = generate_task_list(self.cfg.xres, self.cfg.yres, SEEDSTART, self.seedcount)
         self.seedcount += len(tiles)  # `c = seedcount++` per task, render_driver.cpp:160
-        mine = shard_tiles(tiles, self.rank, self.world_size) if self.world_size > 1 else tiles
-        if self.world_size > 1:
-            ob = EXRTexture(self.cfg.xres, self.cfg.yres, self.device)
+        if self.world_size == 1:
+            torch.cuda.current_stream(self.device).synchronize()
+            cnt = self.scene.render_round_device(self.camera, self.params, tiles, self.total_ob.data.data_ptr(), self.total_ob.count.data_ptr())
         else:
-            ob = self.total_ob
-        torch.cuda.current_stream(self.device).synchronize()
-        cnt = self.scene.render_round_device(self.camera, self.params, mine, ob.data.data_ptr(), ob.count.data_ptr())
-        if self.world_size > 1 and reduce:
-            import torch.distributed as dist
-            if self.host_reduce:
-                hd, hc = ob.data.cpu(), ob.count.cpu()
-                dist.reduce(hd, dst=0, op=dist.ReduceOp.SUM)
-                dist.reduce(hc, dst=0, op=dist.ReduceOp.SUM)
-                if self.rank == 0:
-                    self.total_ob.data += hd.to(self.total_ob.data.device)
-                    self.total_ob.count += hc.to(self.total_ob.count.device)
+            mine = shard_tiles(tiles, self.rank, self.world_size)
+            if self.round_ob is None:  # one private accumulator per rank for the whole frame, cleared per round
+                self.round_ob = EXRTexture(self.cfg.xres, self.cfg.yres, self.device)
             else:
-                dist.reduce(ob.data, dst=0, op=dist.ReduceOp.SUM)
-                dist.reduce(ob.count, dst=0, op=dist.ReduceOp.SUM)
+                self.round_ob.data.zero_()
+                self.round_ob.count.zero_()
+            ob = self.round_ob
+            torch.cuda.current_stream(self.device).synchronize()
+            cnt = self.scene.render_round_device(self.camera, self.params, mine, ob.data.data_ptr(), ob.count.data_ptr())
+            if reduce:
+                import torch.distributed as dist
+                if self.host_reduce:
+                    hd = ob.data.cpu()
+                    dist.reduce(hd, dst=0, op=dist.ReduceOp.SUM)
+                    if self.rank == 0:
+                        self.total_ob.data += hd.to(self.total_ob.data.device)
+                else:
+                    dist.reduce(ob.data, dst=0, op=dist.ReduceOp.SUM)
+                    if self.rank == 0:
+                        self.total_ob.data += ob.data
                 if self.rank == 0:
-                    self.total_ob.data += ob.data
-                    self.total_ob.count += ob.count
+                    self.total_ob.count += int(self.params.multisample)
         self.rounds_done += 1
         self.counters.append(cnt)
         return cnt
+
+    def save_checkpoint(self, path):
+        """Raw-accumulator checkpoint (rgk_accum_save): accumulator + rounds done + the running task counter."""
+        lib = capi.load_product()
+        acc = C.c_void_p()
+        capi.check(lib, lib.rgk_accum_create(self.cfg.xres, self.cfg.yres, self.scene.device, C.byref(acc)))
+        try:
+            a = np.ascontiguousarray(self.total_ob.data.cpu().numpy(), dtype=np.float32)
+            c = np.ascontiguousarray(self.total_ob.count.cpu().numpy()).view(np.uint32)
+            capi.check(lib, lib.rgk_accum_upload(acc, a.ctypes.data, c.ctypes.data))
+            capi.check(lib, lib.rgk_accum_save(acc, str(path).encode(), self.rounds_done, self.seedcount))
+        finally:
+            lib.rgk_accum_destroy(acc)
+
+    def load_checkpoint(self, path):
+        """Resume: the next render_round continues the seed sequence where the saved run stopped."""
+        import torch
+        lib = capi.load_product()
+        acc = C.c_void_p()
+        capi.check(lib, lib.rgk_accum_create(self.cfg.xres, self.cfg.yres, self.scene.device, C.byref(acc)))
+        try:
+            rd_, sc_ = C.c_uint32(0), C.c_uint32(0)
+            capi.check(lib, lib.rgk_accum_load(acc, str(path).encode(), C.byref(rd_), C.byref(sc_)))
+            a = np.empty((self.cfg.yres, self.cfg.xres, 3), np.float32)
+            c = np.empty((self.cfg.yres, self.cfg.xres), np.uint32)
+            capi.check(lib, lib.rgk_accum_download(acc, a.ctypes.data, c.ctypes.data))
+        finally:
+            lib.rgk_accum_destroy(acc)
+        self.total_ob.data.copy_(torch.from_numpy(a))
+        self.total_ob.count.copy_(torch.from_numpy(c.view(np.int32)))
+        self.rounds_done, self.seedcount = rd_.value, sc_.value
+
+    def _continue_timed(self, t0, minutes):
+        go = (self.clock() - t0) / 60.0 < minutes
+        if self.world_size > 1:
+            import torch
+            import torch.distributed as dist
+            flag = torch.tensor([1 if go else 0], dtype=torch.int32, device="cpu" if self.host_reduce else self.device)
+            dist.broadcast(flag, src=0)
+            go = bool(flag.item())
+        return go
 
     def render_frame(self, rounds=None, minutes=None, output_file=None):
         """RenderFrame: Rounds mode (render_driver.cpp:229-235) or Timed mode (:237-247); with `output_file` the
         normalised image is rewritten after every round, as the reference does (rank 0 only)."""
         rounds = self.cfg.render_rounds if rounds is None else rounds
         minutes = self.cfg.render_minutes if minutes is None else minutes
-        t0 = time.time()
+        t0 = self.clock()
 
         def one():
             self.render_round()
@@ -244,6 +294,8 @@ class RenderDriver:
             for _ in range(rounds):
                 one()
         else:
-            while (time.time() - t0) / 60.0 < minutes:
+            # Timed mode (render_driver.cpp:237-247).  With several ranks the decision to start another round is rank 0's,
+            # broadcast to all: ranks reading their own clocks could disagree and leave a reduce unmatched.
+            while self._continue_timed(t0, minutes):
                 one()
         return self.total_ob

@@ -101,7 +101,7 @@ def test_json_comments_and_defaults(tmp_path):
     assert g["kind"] == capi.BXDF_LTC_GGX_DIFFUSE and g["roughness"] == pytest.approx((2 / 202) ** 0.5)
     assert sb.textures[g["tex_diffuse"]]["color"] == (0.0, 0.0, 0.0)          # LTC diffuse fallback is black
     cam = cfg.get_camera()
-    assert cam.yview == pytest.approx(cam.xview * 48 / 64)
+    assert cam.ctor["yview"] == pytest.approx(cam.ctor["xview"] * 48 / 64)
     assert "unused-key" in cfg.perform_post_check() and "url" not in cfg.perform_post_check()
     assert sb.pointlights[0]["color"] == (1.0, 1.0, 1.0)
 
@@ -164,17 +164,23 @@ def test_obj_loader_on_reference_meshes():
     assert all(m["kind"] == capi.BXDF_LTC_GGX_DIFFUSE for m in sb.materials)
 
 
-# ----------------------------------------------------------------------- multi-GPU path on CPU (gloo, world_size 2)
-def _rank_main(rank, world, port, q):
+# ----------------------------------------------------------------------- multi-GPU path on CPU (gloo, world_size 2 and 4)
+def _case_workload(case):
+    from rgk_amd.workloads import SceneFixture, Workload
+    if case == "reverse":  # emissive triangles + BDPT light sub-paths: splats make the reduce a true sum
+        return SceneFixture(os.path.join(ROOT, "tests", "golden", "scene_box6.npz"), scale=0.04, spp=2, depth=3)
+    return Workload("cornell-256", scale=0.25, spp=4)
+
+
+def _rank_main(rank, world, port, q, case):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
     from oracle import rgk_oracle as O
     from rgk_amd import render_driver as rd
-    from rgk_amd.workloads import Workload
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    wl = Workload("cornell-256", scale=0.25, spp=4)
+    wl = _case_workload(case)
     osc = O.OracleScene(wl.builder.to_desc())
 
     class HostScene:  # stands in for the GPU scene: same entry point, host pointers, oracle underneath
@@ -192,36 +198,85 @@ def _rank_main(rank, world, port, q):
     rd.generate_task_list = lambda *a, **k: O.generate_task_list(*a, **k)   # host-only twin (needs no HIP runtime)
     torch.cuda.current_stream = lambda dev=None: type("S", (), {"synchronize": lambda self: None})()
     drv = rd.RenderDriver(HostScene(), Cfg, wl.camera, rank=rank, world_size=world, device=torch.device("cpu"))
-    drv.render_frame()
+    if case == "timed":
+        # skewed clocks: rank 0's clock allows exactly two rounds, every other rank's says the time was up before the first.
+        # The decision is rank 0's (broadcast), so all ranks run two rounds and every reduce is matched.
+        calls = [0]
+
+        def clock():
+            calls[0] += 1
+            return 0.0 if (rank == 0 and calls[0] <= 3) else 1e9  # call 1 is render_frame's own t0
+        if rank != 0:
+            drv.clock = lambda: 1e9
+            drv.render_frame(minutes=1.0)
+        else:
+            drv.clock = clock
+            drv.render_frame(minutes=1.0)
+    else:
+        drv.render_frame()
     rd.generate_task_list = real_tl
-    if rank == 0:
-        q.put((drv.total_ob.data.numpy().copy(), drv.total_ob.count.numpy().copy()))
+    q.put((rank, drv.rounds_done, drv.total_ob.data.numpy().copy() if rank == 0 else None, drv.total_ob.count.numpy().copy() if rank == 0 else None))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_tile_sharding_and_reduce_world_size_2(oracle):
+def _run_ranks(world, case):
     import torch.multiprocessing as mp
-    from rgk_amd.workloads import Workload
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() * 7 + world * 13 + len(case)) % 2000
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, q, case)) for r in range(world)]
     for p in procs:
         p.start()
-    data, count = q.get(timeout=240)
+    got = [q.get(timeout=300) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    # single-process reference: two rounds over the whole tile list
-    wl = Workload("cornell-256", scale=0.25, spp=4)
+    rounds = {r: n for r, n, _, _ in got}
+    data, count = next((d, c) for r, _, d, c in got if r == 0)
+    return rounds, data, count
+
+
+def _single_process(oracle, case, rounds=2):
+    wl = _case_workload(case)
     osc = oracle.OracleScene(wl.builder.to_desc())
     acc = np.zeros((wl.yres, wl.xres, 3), np.float32); cnt = np.zeros((wl.yres, wl.xres), np.uint32)
     n = len(oracle.generate_task_list(wl.xres, wl.yres))
-    for r in range(2):
+    for r in range(rounds):
         osc.render_round(wl.camera, wl.params(), oracle.generate_task_list(wl.xres, wl.yres, seedcount_base=r * n), acc, cnt)
+    return acc, cnt
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_tile_sharding_and_reduce(oracle, world):
+    rounds, data, count = _run_ranks(world, "rounds")
+    assert all(n == 2 for n in rounds.values())
+    acc, cnt = _single_process(oracle, "rounds")  # two rounds over the whole tile list
     assert np.array_equal(count.view(np.uint32), cnt)
     assert np.array_equal(data, acc)      # disjoint tiles: the reduce is exact, the image does not depend on G
+
+
+def test_timed_mode_is_a_collective_decision(oracle):
+    """in timed mode every rank used to read its own clock; a rank that ran one more round left a reduce
+    unmatched.  Rank 0 decides and broadcasts: with badly skewed clocks all ranks still run the same two rounds."""
+    rounds, data, count = _run_ranks(2, "timed")
+    assert rounds == {0: 2, 1: 2}
+    acc, cnt = _single_process(oracle, "timed")
+    assert np.array_equal(count.view(np.uint32), cnt) and np.array_equal(data, acc)
+
+
+def test_reverse_splats_reduce_is_a_true_sum_world_size_4(oracle):
+    """reverse > 0: light-tracing splats land on other ranks' pixels, so the per-round reduce is a true sum -- equal to the
+    single-process image up to float re-association, and bit-identical run to run (fixed reduction order)."""
+    rounds, data, count = _run_ranks(4, "reverse")
+    _, data2, count2 = _run_ranks(4, "reverse")
+    assert all(n == 2 for n in rounds.values())
+    acc, cnt = _single_process(oracle, "reverse")
+    assert np.array_equal(count.view(np.uint32), cnt)         # splats add radiance with count 0 (tracer.cpp:25)
+    rel = np.linalg.norm(data - acc) / np.linalg.norm(acc)
+    print(f"[gloo ws4 reverse] rel-L2 vs single process {rel:.3e}, bit-identical pixels {np.mean(data == acc):.4f}")
+    assert rel < 1e-6
+    assert np.array_equal(data, data2) and np.array_equal(count, count2)
 
 
 # ----------------------------------------------------------------------- output path (SURVEY 8(f) f3)

@@ -42,7 +42,7 @@ def cornell():
     cfg = Config(os.path.join(REF, "scenes", "cornell-box.json"))
     sb = cfg.build_scene()
     cam = cfg.get_camera()
-    extra = dict(camera=dict(pos=list(cam.pos), lookat=list(cam.lookat), up=list(cam.up), fov=19.5),
+    extra = dict(camera=dict(pos=list(cam.ctor["pos"]), lookat=list(cam.ctor["lookat"]), up=list(cam.ctor["up"]), fov=19.5),
                  xres=cfg.xres, yres=cfg.yres, multisample=cfg.multisample, depth=cfg.recursion_level,
                  clamp=float(cfg.clamp), russian=float(cfg.russian), bumpscale=float(cfg.bumpmap_scale),
                  reverse=cfg.reverse, source="scenes/cornell-box.json")
