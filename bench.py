@@ -12,14 +12,16 @@ on the device.
 
 N = 1 workload = the configuration BASELINE.json's metric is quoted on: Sponza
 1920x1080x256spp (scenes/sponza.json + overrides), on the labelled PROXY geometry because
-sponza.obj is absent from the reference checkout.  Scaling is "weak" by
-default: with N GPUs the round takes N x the samples per pixel and the centre-out tile
-list is dealt round-robin, so each GPU traces as many paths as the single GPU does at
-N = 1 (`--scaling strong` keeps the frame's sample count fixed instead).
+sponza.obj is absent from the reference checkout.  Scaling is "strong" by
+default, as the metric reads ("Sponza 1920x1080x256spp at 1/2/4/8 MI355X"): the frame and its
+sample count stay fixed and the centre-out tile list is dealt round-robin, so with N GPUs each
+traces 1/N of the tiles (`--scaling weak` takes N x the samples per pixel instead: fixed work
+per GPU).
 
-The JSON line also carries `roofline` for the dominant kernel (k_trace_closest: HIP-event
-time inside the timed region; algorithmic bytes per SURVEY 8(d)) and, at N = 1,
-`cpu_baseline` (the CPU oracle timed on the host cores on a bounded tile sample).
+The JSON line also carries `roofline` -- the binding ceiling of the dominant kernel with
+frac <= 1 (traversal: VALU issue; shading: HBM), per-kernel records under `kernels`, every
+profile-derived number with its source -- and, at N = 1, `cpu_baseline` (the CPU oracle
+timed on the host cores on a bounded tile sample).
 """
 import argparse
 import json
@@ -58,7 +60,7 @@ def main():
     ap.add_argument("--workload", default="sponza-1080p")
     ap.add_argument("--scale", type=float, default=1.0, help="resolution scale (testing only; invalidates the number)")
     ap.add_argument("--spp", type=int, default=None, help="override samples per pixel (testing only)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + RGK_FORCE_DEVICE=0 rehearses N ranks on one GPU")
@@ -136,53 +138,100 @@ def main():
         tot = local
     paths, path_rays, shadow_rays = tot
 
-    # ---- roofline of the dominant kernel (rank 0's launches): traversal counters from one
-    # extra untimed counting round (deterministic per seed), HIP-event time from the timed steps
-    ms_trace = sum(c.ms_trace for c in cnts)
-    n_launch = sum(c.n_trace_launches for c in cnts)
-    rays_local = sum(c.path_rays for c in cnts)
+    # ---- rooflines.  LIVE in this run: HIP-event time per kernel class inside the timed steps, the traversal counters of one
+    # extra untimed counting round (deterministic per seed), and each class's compulsory STREAMING bytes (queue records it must
+    # read and write once: exact, from the queue counters).  FROM THE COMMITTED PROFILE of this same command
+    # (profiles/<tag>_roofline.json, tools/profile_round.sh + tools/summarize_prof.py): the VALU instruction mix, lane
+    # utilisation and the physical HBM bytes (rocprofv3 --pmc; bench.py cannot run the profiler on itself) -- attached only
+    # when workload, batch and N match the profiled run, and always with their source named.
+    ms = {"k_trace_closest": sum(c.ms_trace for c in cnts), "k_trace_shadow": sum(c.ms_shadow for c in cnts),
+          "k_shade": sum(c.ms_shade for c in cnts), "raygen_resolve": sum(c.ms_other for c in cnts)}
+    nl = {"k_trace_closest": sum(c.n_trace_launches for c in cnts), "k_trace_shadow": sum(c.n_shadow_launches for c in cnts),
+          "k_shade": sum(c.n_shade_launches for c in cnts)}
+    P_l, R_l, S_l = (sum(c.paths for c in cnts), sum(c.path_rays for c in cnts), sum(c.shadow_rays for c in cnts))  # this rank
     drv_c = rd.RenderDriver(scene, Cfg, wl.camera, rank=rank, world_size=world, device=device, flags=capi.FLAG_COUNT_TRAVERSAL,
                             host_reduce=(args.backend != "nccl"))
     cc = drv_c.render_round(reduce=False)
     nodes_per_ray = cc.node_visits / max(1, cc.path_rays)
     tris_per_ray = cc.tri_tests / max(1, cc.path_rays)
-    # per closest-hit ray 32 (ray) + 4 (ignore id) + 16 (hit) + N_node*s_node + N_tri*s_tri
+    # SURVEY 8(d) algorithmic bytes per closest-hit ray: 32 (ray) + 4 (ignore id) + 16 (hit) + N_node*s_node + N_tri*s_tri.
+    # Node and triangle bytes are served by L1 / L2 / Infinity Cache, so this figure is NOT a fraction of HBM bandwidth
+    # (round 1 reported it as one: 1.78); it is kept as the algorithmic rate only.
     bytes_per_ray = 32 + 4 + 16 + nodes_per_ray * info.node_bytes + tris_per_ray * info.tri_bytes
-    alg_bytes = bytes_per_ray * rays_local
-    achieved = alg_bytes / (ms_trace * 1e-3) / 1e9 if ms_trace > 0 else 0.0
-    # physical HBM-side traffic per launch of that kernel: FETCH_SIZE (x2, gfx950) + WRITE_SIZE from the committed
-    # rocprofv3 --pmc passes of this same command (profiles/<round>_hbm_traffic.csv); bench.py cannot run the
-    # profiler on itself, so the value is only attached when workload and batch match the profiled run
-    traffic = None
+    stream = {  # bytes every launch of the class must move through HBM once (records in, records out), summed over the timed steps
+        "k_trace_closest": 48.0 * R_l,                                   # ray 32 in, hit 16 out
+        "k_trace_shadow": 48.0 * S_l,                                    # shadow ray 48 in (+ the slot sums of visible ones)
+        "k_shade": 68.0 * R_l + 64.0 * (R_l - P_l) + 48.0 * S_l,         # ray 32 + hit 16 + light 16 + seed 4; thr 16 w + 16 r and next ray 32 per continuing path; shadow ray 48 out
+        "raygen_resolve": (64.0 + 8.0 + 16.0) * P_l,                     # raygen: ray 32 + light 16 + slot sum 16 out, pixel + seed 8 in; resolve: slot sum 16 in
+    }
+    prof, prof_name = None, None
     try:
-        import csv
         if args.workload == "sponza-1080p" and args.scale == 1.0 and args.spp is None and world == 1:
-            prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_hbm_traffic.csv"))[-1]
-            for row in csv.DictReader(open(os.path.join(ROOT, "profiles", prof))):
-                if row["kernel"].startswith("k_trace_closest<false"):
-                    traffic = float(row["hbm_MB_per_launch"]) * 1e6
+            prof_name = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_roofline.json"))[-1]
+            prof = json.load(open(os.path.join(ROOT, "profiles", prof_name)))["kernels"]
     except Exception:
-        traffic = None
-    roofline = {"bound": "hbm", "kernel": "k_trace_closest", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-                "alg_bytes_per_launch": round(alg_bytes / max(1, n_launch), 1),
-                "launches": n_launch, "avg_launch_ms": round(ms_trace / max(1, n_launch), 4),
-                "alg_bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(nodes_per_ray, 2),
-                "tris_per_ray": round(tris_per_ray, 2), "node_bytes": info.node_bytes, "tri_bytes": info.tri_bytes,
-                "other_kernels_ms": {"k_trace_shadow": round(sum(c.ms_shadow for c in cnts), 2),
-                                     "k_shade": round(sum(c.ms_shade for c in cnts), 2),
-                                     "raygen_resolve": round(sum(c.ms_other for c in cnts), 2)}}
+        prof = None
 
+    def prof_rec(kernel):
+        if not prof:
+            return None
+        for k, r in prof.items():  # the non-counting instantiation of the template
+            if k.startswith(kernel) and "<true" not in k and (kernel != "k_shade" or k.startswith("k_shade<false>")):
+                return r
+        return None
+
+    kernels = []
+    for k in ("k_trace_closest", "k_shade", "k_trace_shadow", "raygen_resolve"):
+        t = ms[k] * 1e-3
+        rec = {"kernel": k, "ms_per_step": round(ms[k] / args.steps, 3), "launches": nl.get(k),
+               "avg_launch_ms": round(ms[k] / max(1, nl.get(k, 0)), 4) if nl.get(k) else None,
+               "stream_GBps": round(stream[k] / t / 1e9, 1) if t > 0 else None,
+               "stream_frac_of_hbm": round(stream[k] / t / 8.0e12, 4) if t > 0 else None}
+        pr = prof_rec(k)
+        if pr and rec["avg_launch_ms"]:
+            live_s = rec["avg_launch_ms"] * 1e-3
+            rec.update({
+                "source": f"profiles/{prof_name}", "profile_avg_launch_ms": pr["avg_ms"],
+                # VALU issue: instruction-class counts x measured issue cycles, against 1024 SIMDs x 2.4 GHz x the LIVE launch time
+                "valu_issue_frac": round(pr["valu_issue_cycles"] / (1024 * 2.4e9 * live_s), 4),
+                "valu_issue_frac_at_measured_clock": pr["valu_issue_frac"], "lane_util": pr["lane_util"],
+                "hbm_bytes_per_launch": pr.get("hbm_bytes_per_launch"),
+                "hbm_frac": round(pr["hbm_bytes_per_launch"] / live_s / 8.0e12, 4) if pr.get("hbm_bytes_per_launch") else None})
+        kernels.append(rec)
+    dom = max(kernels[:3], key=lambda r: r["ms_per_step"])
+    if dom["kernel"] == "k_shade":      # gathers + queue records: bounded by the memory system
+        bound, unit, peak = "hbm", "GB/s", 8000.0
+        achieved = (dom["hbm_bytes_per_launch"] / (dom["avg_launch_ms"] * 1e-3) / 1e9) if dom.get("hbm_bytes_per_launch") else dom["stream_GBps"]
+        traffic = dom.get("hbm_bytes_per_launch")
+    else:                                # traversal: bounded by VALU issue, not by HBM
+        bound, unit, peak = "valu", "G SIMD-cycles/s", 1024 * 2.4
+        pr = prof_rec(dom["kernel"])
+        achieved = (pr["valu_issue_cycles"] / (dom["avg_launch_ms"] * 1e-3) / 1e9) if pr else None
+        traffic = dom.get("hbm_bytes_per_launch")
+    roofline = {"bound": bound, "kernel": dom["kernel"], "achieved": round(achieved, 1) if achieved else None, "peak": peak, "unit": unit,
+                "frac": round(achieved / peak, 4) if achieved else None, "traffic": traffic,
+                "traffic_source": f"profiles/{prof_name} (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE of this command)" if traffic else None,
+                "lane_util": dom.get("lane_util"), "hbm_frac": dom.get("hbm_frac"),
+                "algorithmic": {"note": "SURVEY 8(d) bytes per ray over launch time; cache-served, not an HBM fraction",
+                                "GBps": round(bytes_per_ray * R_l / (ms["k_trace_closest"] * 1e-3) / 1e9, 1) if ms["k_trace_closest"] > 0 else None,
+                                "bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(nodes_per_ray, 2), "tris_per_ray": round(tris_per_ray, 2),
+                                "node_bytes": info.node_bytes, "tri_bytes": info.tri_bytes,
+                                "rays_per_s_closest": round(R_l / (ms["k_trace_closest"] * 1e-3) / 1e9, 3) if ms["k_trace_closest"] > 0 else None},
+                "kernels": kernels}
+
+    metric_name = {"sponza-1080p": "Sponza 1920x1080x256spp", "cornell-1024": "Cornell box 1024x1024x256spp", "cornell-256": "Cornell box 256x256x16spp",
+                   "dragon-sponza-1080p": "Dragon-Sponza 1920x1080x512spp reverse 3", "sponza4-2160p": "Sponza4 3840x2160x1024spp"}[args.workload]
     out = {
-        "metric": "Mpaths/s, Sponza 1920x1080x256spp (path-tracing hot path)",
+        "metric": f"Mpaths/s, {metric_name} (path-tracing hot path)",
         "value": round(paths / elapsed / 1e6, 2), "unit": "Mpaths/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.workload} {wl.xres}x{wl.yres}x{wl.multisample}spp depth {wl.depth} russian {wl.russian:.2f}",
+        "config": {"workload": f"{args.workload} {wl.xres}x{wl.yres}x{wl.multisample}spp depth {wl.depth} russian {wl.russian:.2f}, {args.scaling} scaling"
+                               + ("" if args.scale == 1.0 and args.spp is None else " (REDUCED SIZE: not the benchmark number)"),
                    "geometry": wl.geometry, "triangles": int(len(wl.builder.F)), "sampler": "halton-cp",
-                   "tiles": drv.n_tasks, "parallelism": f"tiles round-robin over {world} GPU(s) + RCCL reduce"},
+                   "tiles": drv.n_tasks, "parallelism": f"tiles round-robin over {world} GPU(s) + one RCCL reduce per round"},
         "mrays_per_s_path": round(path_rays / elapsed / 1e6, 2),
         "mrays_per_s_all": round((path_rays + shadow_rays) / elapsed / 1e6, 2),
         "roofline": roofline,

@@ -12,6 +12,30 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Every parity test records what it MEASURED (not only whether it passed); the table is printed at the end of the run and
+# appended to gpurun_out/parity_measured.txt, so the margin to each stated tolerance is on record.
+PARITY = []
+
+
+def record_parity(test, **measured):
+    PARITY.append((test, measured))
+
+
+def pytest_terminal_summary(terminalreporter):
+    if not PARITY:
+        return
+    lines = [f"{t:58s} " + "  ".join(f"{k}={v:.4g}" if isinstance(v, float) else f"{k}={v}" for k, v in m.items()) for t, m in PARITY]
+    terminalreporter.write_sep("-", "parity: measured values")
+    for ln in lines:
+        terminalreporter.write_line(ln)
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "parity_measured.txt"), "w") as f:
+            f.write("\n".join(lines) + "\n")
+    except OSError:
+        pass
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import rgk_oracle as O

@@ -61,6 +61,64 @@ def test_host_argument_errors_need_no_gpu(product_lib):
     assert product_lib.rgk_scene_create(C.byref(d), 0, C.byref(h)) == -1 and not h.value                  # empty scene
 
 
+def test_camera_constructor_equals_the_oracles(product_lib, oracle):
+    """rgk_camera_init (host code of the product) against the oracle's own restatement of Camera::Camera
+    (src/camera.cpp:7-24): the derived members RenderRound's `const Camera&` carries, bit for bit."""
+    rng = np.random.default_rng(11)
+    L = oracle.lib()
+    for k in range(200):
+        pos, la = rng.normal(size=3).astype(np.float32) * 10, rng.normal(size=3).astype(np.float32) * 10
+        up = (0.0, 1.0, 0.0) if k % 2 else tuple(rng.normal(size=3).astype(np.float32))
+        yview, xview = np.float32(rng.uniform(0.2, 2.0)), np.float32(rng.uniform(0.2, 2.0))
+        fp, ls = np.float32(rng.uniform(0.5, 5.0)), np.float32(0.0 if k % 3 else 0.1)
+        a, b = capi.Camera(), capi.Camera()
+        args = (capi.f3(*map(float, pos)), capi.f3(*map(float, la)), capi.f3(*map(float, up)), float(yview), float(xview), 640, 480, float(fp), float(ls))
+        assert product_lib.rgk_camera_init(C.byref(a), *args) == 0
+        assert L.orc_camera_init(C.byref(b), *args) == 0
+        assert bytes(a) == bytes(b)
+    assert product_lib.rgk_camera_init(None, *args) == -1
+
+
+def test_mix_nesting_is_validated_without_a_gpu(product_lib):
+    """BxDFMix recurses (bxdf.cpp:235-249); the kernels evaluate two levels.  Deeper nesting and cycles are refused by
+    rgk_scene_create's descriptor check (before any device is touched) instead of being rendered wrong."""
+    from rgk_amd.scene import SceneBuilder
+    def scene_with(mats):
+        sb = SceneBuilder.load_npz(os.path.join(ROOT, "rgk_amd", "data", "cornell_scene.npz"))
+        base = dict(sb.materials[0])
+        sb.materials = [dict(base, name=f"x{i}", **m) for i, m in enumerate(mats)] + sb.materials
+        sb.tri_mat = [sb.FM + len(mats)]
+        sb.FM = None
+        return sb
+    leaf = dict(kind=capi.BXDF_DIFFUSE)
+    mix = lambda a, b: dict(kind=capi.BXDF_MIX, mix_m1=a, mix_m2=b, amount=0.5)
+    h = C.c_void_p()
+    ok2 = scene_with([leaf, leaf, mix(0, 1), mix(2, 0)])            # mix of (mix of leaves): two levels
+    rc = product_lib.rgk_scene_create(C.byref(ok2.to_desc()), 0, C.byref(h))
+    assert rc in (0, -4), product_lib.rgk_last_error()               # accepted: created, or no device in this container
+    if rc == 0:
+        product_lib.rgk_scene_destroy(h)
+    deep = scene_with([leaf, leaf, mix(0, 1), mix(2, 0), mix(3, 1)])  # three levels
+    assert product_lib.rgk_scene_create(C.byref(deep.to_desc()), 0, C.byref(h)) == -5
+    assert b"nested 3 levels" in product_lib.rgk_last_error()
+    cyc = scene_with([leaf, mix(2, 0), mix(1, 0)])                    # 1 -> 2 -> 1
+    assert product_lib.rgk_scene_create(C.byref(cyc.to_desc()), 0, C.byref(h)) == -1
+    assert b"cycle" in product_lib.rgk_last_error()
+
+
+def test_shard_tiles_is_a_round_robin_deal(product_lib):
+    from rgk_amd import render_driver as rd
+    tiles = rd.generate_task_list(1920, 1080, 42, 5)
+    seen = []
+    for rank in range(8):
+        mine = rd.shard_tiles(tiles, rank, 8)
+        assert [(t.x0, t.y0, t.seed) for t in mine] == [(tiles[i].x0, tiles[i].y0, tiles[i].seed) for i in range(rank, len(tiles), 8)]
+        seen += [(t.x0, t.y0) for t in mine]
+    assert sorted(seen) == sorted((t.x0, t.y0) for t in tiles)
+    n = C.c_uint32(0)
+    assert product_lib.rgk_shard_tiles(tiles, len(tiles), 8, 8, None, C.byref(n)) == -1
+
+
 def test_product_fails_loudly_without_the_extension(monkeypatch):
     monkeypatch.setattr(capi, "LIB_PATH", "/nonexistent/librgk_hip.so")
     monkeypatch.setattr(capi, "_product", None)

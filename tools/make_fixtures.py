@@ -13,6 +13,8 @@ needs /root/reference).  Fixtures are DATA: inputs and expected outputs.
                      rubiks-bump (PNG texture + bump map, point light), cube3 (8966 faces, global
                      ltc_beckmann override, sphere light), box6 (17 k triangles with uv, emissive
                      triangles, reverse = 3), cornell-box-spheres (LTC Beckmann + dielectric spheres).
+  rgk_amd/data/sponza_textures_u8.npz  the 17 JPGs shipped under scenes/sponza-fixed/ as decoded bytes (the Sponza proxy's
+                     textures; the mesh itself is absent from the reference checkout).
 """
 import os
 import subprocess
@@ -85,10 +87,30 @@ def cornell_image():
     print("cornell_config0_half.npz", acc.shape, int(k.paths), "paths")
 
 
+def sponza_textures():
+    """The 17 JPGs the reference ships for Sponza (scenes/sponza-fixed/*.JPG; Dabrovic Sponza, (c) 2002 Marko Dabrovic, bump
+    maps by Morgan McGuire -- scenes/sponza-fixed/copyright.txt), decoded ONCE here with PIL into the bytes an 8-bit loader
+    holds (h, w, 3 uint8, top row first): both the oracle and the HIP path then see the same texels whatever JPEG decoder
+    a machine has.  The proxy geometry is uv-mapped onto them through the 20 sponza.mtl materials."""
+    from PIL import Image
+    d = os.path.join(REF, "scenes", "sponza-fixed")
+    arrs = {}
+    for f in sorted(os.listdir(d)):
+        if f.lower().endswith(".jpg"):
+            arrs[f] = np.asarray(Image.open(os.path.join(d, f)).convert("RGB"), dtype=np.uint8)
+    out = os.path.join(ROOT, "rgk_amd", "data", "sponza_textures_u8.npz")
+    np.savez_compressed(out, **arrs)
+    print("sponza_textures_u8.npz", len(arrs), "images", sum(a.nbytes for a in arrs.values()), "bytes decoded,", os.path.getsize(out), "on disk")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "sponza_textures":
+        sponza_textures()
+        sys.exit(0)
     halton()
     cornell()
     cornell_image()
     for n in REFERENCE_SCENES:
         reference_scene(n)
+    sponza_textures()

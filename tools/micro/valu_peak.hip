@@ -41,6 +41,11 @@ __global__ __launch_bounds__(256, 8) void k(unsigned long long* stamps, float* s
             if (KIND == 17) { asm volatile("v_cndmask_b32_e64 %0, %2, %3, %4\nv_cndmask_b32_e64 %1, %2, %3, %4\nv_cndmask_b32_e64 %0, %2, %3, %4\nv_cndmask_b32_e64 %1, %2, %3, %4\nv_cndmask_b32_e64 %0, %2, %3, %4\nv_cndmask_b32_e64 %1, %2, %3, %4\nv_cndmask_b32_e64 %0, %2, %3, %4\nv_cndmask_b32_e64 %1, %2, %3, %4" : "+v"(a), "+v"(b) : "v"(m), "v"(c), "s"(0x5555555555555555ull)); }
             if (KIND == 18) { asm volatile("v_cmp_lt_f32_e64 %2, %0, %1\nv_cmp_lt_f32_e64 %2, %1, %0\nv_cmp_lt_f32_e64 %2, %0, %1\nv_cmp_lt_f32_e64 %2, %1, %0\nv_cmp_lt_f32_e64 %2, %0, %1\nv_cmp_lt_f32_e64 %2, %1, %0\nv_cmp_lt_f32_e64 %2, %0, %1\nv_cmp_lt_f32_e64 %2, %1, %0" : "+v"(a), "+v"(b), "=s"(sm)); }
             if (KIND == 19) { asm volatile("v_mul_f32_e32 %0, %0, %2\nv_add_f32_e32 %1, %1, %2\nv_mul_f32_e32 %0, %0, %2\nv_add_f32_e32 %1, %1, %2\nv_mul_f32_e32 %0, %0, %2\nv_add_f32_e32 %1, %1, %2\nv_mul_f32_e32 %0, %0, %2\nv_add_f32_e32 %1, %1, %2" : "+v"(a), "+v"(b) : "v"(m)); }
+            if (KIND == 20) { asm volatile("v_mov_b32_e32 %0, %2\nv_mov_b32_e32 %1, %2\nv_mov_b32_e32 %0, %2\nv_mov_b32_e32 %1, %2\nv_mov_b32_e32 %0, %2\nv_mov_b32_e32 %1, %2\nv_mov_b32_e32 %0, %2\nv_mov_b32_e32 %1, %2" : "+v"(a), "+v"(b) : "v"(m)); }
+            if (KIND == 21) { asm volatile("v_add_u32_e32 %0, %0, %2\nv_add_u32_e32 %1, %1, %2\nv_add_u32_e32 %0, %0, %2\nv_add_u32_e32 %1, %1, %2\nv_add_u32_e32 %0, %0, %2\nv_add_u32_e32 %1, %1, %2\nv_add_u32_e32 %0, %0, %2\nv_add_u32_e32 %1, %1, %2" : "+v"(a), "+v"(b) : "v"(m)); }
+            if (KIND == 22) { asm volatile("v_lshlrev_b32_e32 %0, 3, %2\nv_lshlrev_b32_e32 %1, 5, %2\nv_lshlrev_b32_e32 %0, 3, %2\nv_lshlrev_b32_e32 %1, 5, %2\nv_lshlrev_b32_e32 %0, 3, %2\nv_lshlrev_b32_e32 %1, 5, %2\nv_lshlrev_b32_e32 %0, 3, %2\nv_lshlrev_b32_e32 %1, 5, %2" : "+v"(a), "+v"(b) : "v"(m)); }
+            if (KIND == 23) { asm volatile("v_add_f64 %0, %0, %2\nv_mul_f64 %1, %1, %2\nv_add_f64 %0, %0, %2\nv_mul_f64 %1, %1, %2\nv_add_f64 %0, %0, %2\nv_mul_f64 %1, %1, %2\nv_add_f64 %0, %0, %2\nv_mul_f64 %1, %1, %2" : "+v"(da), "+v"(db) : "v"(dm)); }
+            if (KIND == 24) { asm volatile("v_div_scale_f32 %0, vcc, %0, %2, %0\nv_div_fixup_f32 %1, %1, %2, %3\nv_div_scale_f32 %0, vcc, %0, %2, %0\nv_div_fixup_f32 %1, %1, %2, %3\nv_div_scale_f32 %0, vcc, %0, %2, %0\nv_div_fixup_f32 %1, %1, %2, %3\nv_div_scale_f32 %0, vcc, %0, %2, %0\nv_div_fixup_f32 %1, %1, %2, %3" : "+v"(a), "+v"(b) : "v"(m), "v"(c) : "vcc"); }
             if (KIND == 9) { asm volatile("v_sqrt_f32_e32 %0, %0\nv_sqrt_f32_e32 %1, %1\nv_sqrt_f32_e32 %0, %0\nv_sqrt_f32_e32 %1, %1\nv_sqrt_f32_e32 %0, %0\nv_sqrt_f32_e32 %1, %1\nv_sqrt_f32_e32 %0, %0\nv_sqrt_f32_e32 %1, %1" : "+v"(a), "+v"(b)); }
         }
     }
@@ -83,6 +88,7 @@ int main() {
     run<1>("v_cvt_f32_ubyteN", 64); run<2>("v_max3/min3_f32", 64); run<3>("v_cndmask_b32", 64);
     run<10>("v_perm_b32", 64); run<11>("v_and_or_b32", 64); run<12>("v_bfe_u32", 64); run<13>("v_cvt_f32_u32", 64); run<14>("v_cvt_f32_u32_sdwa", 64);
     run<15>("v_fma_mix_f32", 64); run<16>("v_max/min_f32", 64); run<17>("v_cndmask_b32_e64", 64); run<18>("v_cmp_lt_f32_e64", 64); run<19>("v_mul/add_f32", 64);
+    run<20>("v_mov_b32", 64); run<21>("v_add_u32", 64); run<22>("v_lshlrev_b32", 64); run<23>("v_add/mul_f64", 64); run<24>("v_div_scale/fixup_f32", 64);
     run<4>("v_fma_f64", 64); run<5>("v_rcp_f32", 64); run<9>("v_sqrt_f32", 64); run<6>("v_mul_lo_u32", 64); run<7>("v_pk_fma_f32", 64); run<8>("v_rcp_f64", 64);
     return 0;
 }

@@ -1,16 +1,21 @@
 #!/bin/bash
-# On the GPU box: kernel-trace stats of the default bench run + the two HBM-traffic counter passes (counters on their own).
-# usage: tools/profile_round.sh <tag>; then locally: python tools/summarize_prof.py <tag> gpurun_out/prof_<tag>_stats gpurun_out/prof_<tag>_fetch gpurun_out/prof_<tag>_write
-tag=$1
+# On the GPU box: the profiles a round commits under profiles/ -- kernel-trace stats of the default bench run, the two
+# HBM-traffic counter passes and the VALU instruction-class passes (tools/pmc_roofline.txt); counters always on their own.
+# usage: tools/profile_round.sh <tag> [bench args]; then locally: python tools/summarize_prof.py <tag>
+tag=$1; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-for d in stats fetch write; do rm -rf $R/gpurun_out/prof_${tag}_$d; done
+rm -rf $R/gpurun_out/prof_${tag}_*
 echo "stats pass"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${tag}_stats --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_${tag}_bench.json 2> $R/gpurun_out/prof_${tag}_stats.err || exit 1
-echo "fetch pass"
-timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/prof_${tag}_fetch --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/prof_${tag}_fetch.err || exit 1
-echo "write pass"
-timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/prof_${tag}_write --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/prof_${tag}_write.err || exit 1
-# the kernel trace itself is large: keep only the stats tables
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${tag}_stats --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $R/gpurun_out/prof_${tag}_bench.json 2> $R/gpurun_out/prof_${tag}_stats.err || exit 1
+i=0
+while read -r line; do
+  [ -z "$line" ] && continue
+  i=$((i+1))
+  echo "pmc pass $i: $line"
+  timeout -k 10 400 rocprofv3 --pmc $line -d $R/gpurun_out/prof_${tag}_pmc$i --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > /dev/null 2> $R/gpurun_out/prof_${tag}_pmc$i.err || exit 1
+done < <(echo FETCH_SIZE; echo WRITE_SIZE; cat $R/tools/pmc_roofline.txt)
+# the traces themselves are large: keep the stats tables and the counter tables only
 find $R/gpurun_out/prof_${tag}_stats -name "*kernel_trace.csv" -delete
-cat $R/gpurun_out/prof_${tag}_bench.json | cut -c1-300
+find $R/gpurun_out -path "*prof_${tag}_*" -name "*agent_info.csv" -delete
+cut -c1-400 $R/gpurun_out/prof_${tag}_bench.json

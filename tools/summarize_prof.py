@@ -1,23 +1,39 @@
 #!/usr/bin/env python3
-"""Condense rocprofv3 output (gpurun_out/prof_*) into the small files kept under profiles/.
+"""Condense rocprofv3 output (gpurun_out/prof_<tag>_*, written by tools/profile_round.sh) into the small files kept
+under profiles/ -- the evidence bench.py's `roofline` object points at.
 
-  python tools/summarize_prof.py <round-tag> <stats_dir> [<fetch_dir> <write_dir>]
-Writes profiles/<tag>_kernel_stats.csv (the --stats table, kernel names shortened) and
-profiles/<tag>_hbm_traffic.csv (per kernel: launches, FETCH_SIZE / WRITE_SIZE sums in KB as
-reported, and bytes per launch with the gfx950 correction FETCH x2 of MI355X_MICROARCH.md).
+  python tools/summarize_prof.py <round-tag>
+
+  profiles/<tag>_kernel_stats.csv   the --kernel-trace --stats table of the default bench command (kernel names shortened)
+  profiles/<tag>_hbm_traffic.csv    per kernel: FETCH_SIZE / WRITE_SIZE (separate --pmc passes) and bytes per launch with
+                                    the gfx950 correction FETCH x 2 of MI355X_MICROARCH.md (HBM section)
+  profiles/<tag>_roofline.json      per kernel: average launch duration, the VALU instruction mix (SQ_INSTS_VALU_* classes),
+                                    the VALU ISSUE time it implies under the measured issue costs below, the shader cycles the
+                                    kernel had (GRBM_GUI_ACTIVE / 8 XCDs, same pass), lane utilisation, HBM bytes per launch
+
+VALU issue costs, shader cycles one SIMD spends per wave64 instruction with 4 waves per SIMD issuing nothing else
+(tools/micro/valu_peak.hip on MI355X, profiles/<tag>_valu_issue_costs.txt): only fp32 add / mul / fma run at the SIMD-32
+rate of 2; everything else measured -- conversions, min / max / max3, compares, selects, integer and bit operations, moves,
+fp64 add / mul / fma, packed fp32 -- takes 4; transcendentals (rcp, sqrt, ...) 8; v_rcp_f64 16.
+    issue_cycles = 2 (ADD_F32 + MUL_F32 + FMA_F32) + 8 TRANS_F32 + 4 (everything else)
+    valu_issue_frac = issue_cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)          both from the same counter pass
+    lane_util       = SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU)
+    valu_lane_frac  = valu_issue_frac x lane_util      (useful lane-cycles over available lane-cycles)
 """
 import collections
 import csv
 import glob
+import json
 import os
 import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+N_SIMD, N_XCD, HBM_PEAK = 1024, 8, 8.0e12
+COST = {"f32_add_mul_fma": 2, "trans_f32": 8, "other": 4}
 
 
 def short(name):
-    name = name.replace("void ", "")
-    return name.split("(")[0]
+    return name.replace("void ", "").split("(")[0]
 
 
 def find(d, suffix):
@@ -25,37 +41,87 @@ def find(d, suffix):
     return f[0] if f else None
 
 
+def counters(d):
+    """{kernel: {counter: (sum, launches)}} of one --pmc pass directory."""
+    out = collections.OrderedDict()
+    f = find(d, "_counter_collection.csv")
+    if not f:
+        return out
+    disp = collections.defaultdict(lambda: collections.defaultdict(set))
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        c = out.setdefault(k, collections.defaultdict(float))
+        c[r["Counter_Name"]] += float(r["Counter_Value"])
+        disp[k][r["Counter_Name"]].add(r["Dispatch_Id"])
+    return collections.OrderedDict((k, {c: (v, len(disp[k][c])) for c, v in cs.items()}) for k, cs in out.items())
+
+
 def main():
-    tag, stats_dir = sys.argv[1], sys.argv[2]
+    tag = sys.argv[1]
+    base = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_")
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
-    ks = find(stats_dir, "_kernel_stats.csv")
+    stats = {}
+    ks = find(base + "stats", "_kernel_stats.csv")
     with open(ks) as f, open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w", newline="") as g:
         w = csv.writer(g)
         for i, row in enumerate(csv.reader(f)):
             if i:
                 row[0] = short(row[0])
+                stats[row[0]] = {"calls": int(row[1]), "avg_ms": float(row[3]) / 1e6, "pct": float(row[4])}
             w.writerow(row)
-    if len(sys.argv) >= 5:
-        agg = collections.OrderedDict()
-        for d, ctr in ((sys.argv[3], "FETCH_SIZE"), (sys.argv[4], "WRITE_SIZE")):
-            for r in csv.DictReader(open(find(d, "_counter_collection.csv"))):
-                if r["Counter_Name"] != ctr:
-                    continue
-                k = short(r["Kernel_Name"])
-                a = agg.setdefault(k, {"FETCH_SIZE": [0, 0.0], "WRITE_SIZE": [0, 0.0]})
-                a[ctr][0] += 1
-                a[ctr][1] += float(r["Counter_Value"])
-        with open(os.path.join(out, f"{tag}_hbm_traffic.csv"), "w", newline="") as g:
-            w = csv.writer(g)
-            w.writerow(["kernel", "launches", "FETCH_SIZE_KB_sum", "WRITE_SIZE_KB_sum", "read_MB_per_launch_x2corrected",
-                        "write_MB_per_launch", "hbm_MB_per_launch"])
-            for k, a in agg.items():
-                n = max(a["FETCH_SIZE"][0], a["WRITE_SIZE"][0], 1)
-                rd = 2.0 * a["FETCH_SIZE"][1] * 1024 / n / 1e6
-                wr = a["WRITE_SIZE"][1] * 1024 / max(a["WRITE_SIZE"][0], 1) / 1e6
-                w.writerow([k, n, round(a["FETCH_SIZE"][1], 1), round(a["WRITE_SIZE"][1], 1), round(rd, 2), round(wr, 2),
-                            round(rd + wr, 2)])
+    merged = collections.OrderedDict()
+    for d in sorted(x for x in glob.glob(base + "pmc*") if os.path.isdir(x)):
+        for k, cs in counters(d).items():
+            m = merged.setdefault(k, {})
+            has_classes = "SQ_INSTS_VALU_FMA_F32" in cs  # the pass whose shader cycles the issue fraction is taken against
+            for c, vn in cs.items():
+                if c == "GRBM_GUI_ACTIVE" and has_classes:
+                    m[c] = vn
+                else:
+                    m.setdefault(c, vn)
+    with open(os.path.join(out, f"{tag}_hbm_traffic.csv"), "w", newline="") as g:
+        w = csv.writer(g)
+        w.writerow(["kernel", "launches", "FETCH_SIZE_KB_sum", "WRITE_SIZE_KB_sum", "read_MB_per_launch_x2corrected", "write_MB_per_launch", "hbm_MB_per_launch"])
+        for k, m in merged.items():
+            if "FETCH_SIZE" not in m or "WRITE_SIZE" not in m:
+                continue
+            (fv, fn), (wv, wn) = m["FETCH_SIZE"], m["WRITE_SIZE"]
+            rd, wr = 2.0 * fv * 1024 / max(fn, 1) / 1e6, wv * 1024 / max(wn, 1) / 1e6
+            w.writerow([k, max(fn, wn), round(fv, 1), round(wv, 1), round(rd, 2), round(wr, 2), round(rd + wr, 2)])
+    roof = {"tag": tag, "command": "python bench.py --steps 1 --warmup 0 --no-cpu-baseline (one rocprofv3 --pmc pass per counter group); "
+                                   "durations from the --kernel-trace --stats pass of bench.py --steps 3 --warmup 1",
+            "valu_issue_cost_cycles": COST, "n_simd": N_SIMD, "hbm_peak_GBps": HBM_PEAK / 1e9, "kernels": {}}
+    for k, m in merged.items():
+        if not k.startswith("k_") or k not in stats or "SQ_INSTS_VALU" not in m:
+            continue
+        per = lambda c: (m[c][0] / max(m[c][1], 1)) if c in m else 0.0
+        insts = per("SQ_INSTS_VALU")
+        fast = per("SQ_INSTS_VALU_ADD_F32") + per("SQ_INSTS_VALU_MUL_F32") + per("SQ_INSTS_VALU_FMA_F32")
+        trans = per("SQ_INSTS_VALU_TRANS_F32")
+        f64 = per("SQ_INSTS_VALU_ADD_F64") + per("SQ_INSTS_VALU_MUL_F64") + per("SQ_INSTS_VALU_FMA_F64")
+        ints = per("SQ_INSTS_VALU_INT32") + per("SQ_INSTS_VALU_INT64")
+        other = max(insts - fast - trans, 0.0)
+        issue = COST["f32_add_mul_fma"] * fast + COST["trans_f32"] * trans + COST["other"] * other
+        cyc = per("GRBM_GUI_ACTIVE") / N_XCD
+        lane = per("SQ_THREAD_CYCLES_VALU") / (64.0 * insts) if insts else 0.0
+        rec = {"launches_profiled": m["SQ_INSTS_VALU"][1], "avg_ms": round(stats[k]["avg_ms"], 4), "pct_of_gpu_time": stats[k]["pct"],
+               "insts_valu": insts, "insts_f32_add_mul_fma": fast, "insts_trans_f32": trans, "insts_f64": f64, "insts_int": ints,
+               "valu_issue_cycles": issue, "shader_cycles": cyc,
+               "valu_issue_frac": round(issue / (N_SIMD * cyc), 4) if cyc else None, "lane_util": round(lane, 4),
+               "valu_lane_frac": round(issue / (N_SIMD * cyc) * lane, 4) if cyc else None}
+        if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+            b = 2.0 * per("FETCH_SIZE") * 1024 + per("WRITE_SIZE") * 1024
+            rec["hbm_bytes_per_launch"] = b
+            rec["hbm_GBps"] = round(b / (stats[k]["avg_ms"] * 1e-3) / 1e9, 1)
+            rec["hbm_frac"] = round(b / (stats[k]["avg_ms"] * 1e-3) / HBM_PEAK, 4)
+        roof["kernels"][k] = rec
+    json.dump(roof, open(os.path.join(out, f"{tag}_roofline.json"), "w"), indent=1)
+    for k, r in roof["kernels"].items():
+        print(f"{k:34s} {r['avg_ms']:9.3f} ms  valu_issue {r['valu_issue_frac']}  lane {r['lane_util']}  hbm {r.get('hbm_frac')}")
+    micro = os.path.join(ROOT, "gpurun_out", "r2_valu_peak.txt")
+    if os.path.exists(micro):
+        open(os.path.join(out, f"{tag}_valu_issue_costs.txt"), "w").write(open(micro).read())
 
 
 if __name__ == "__main__":
