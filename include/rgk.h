@@ -295,6 +295,19 @@ int rgk_trace_closest(rgk_scene *scene, uint32_t n, const float *rays, const int
 int rgk_trace_visibility(rgk_scene *scene, uint32_t n, const float *a, const float *b,
                          uint8_t *visible, rgk_counters *counters);
 
+/* BxDF::value(Vi, Vr, texUV) and BxDF::sample(Vi, texUV, sample) (src/bxdf/bxdf.hpp:38-43) of material mat[i], for n
+ * inputs, in the local frame (+Z = shading normal).  Unit-level seams for the parity tests.  route 0: the generic code (every
+ * material kind, mixes included); route 1: what the shading kernel runs for diffuse / LTC materials (texture colours and LTC
+ * table entries fetched once and shared between value and sample).  Vi, Vr, out_*: 3 floats each; uv, u: 2 floats each. */
+int rgk_bxdf_value(rgk_scene *scene, uint32_t n, uint32_t route, const uint32_t *mat, const float *Vi, const float *Vr,
+                   const float *uv, float *out_rgb);
+int rgk_bxdf_sample(rgk_scene *scene, uint32_t n, uint32_t route, const uint32_t *mat, const float *Vi, const float *uv,
+                    const float *u, float *out_dir, float *out_weight, uint8_t *may_leak);
+/* ReadableTexture::GetPixelInterpolated, GetSlopeRight, GetSlopeBottom (src/texture.cpp:35-102, src/texture.hpp:64-80) of
+ * descriptor texture tex[i] (-1: EmptyTexture) at uv[i]. */
+int rgk_texture_sample(rgk_scene *scene, uint32_t n, const int32_t *tex, const float *uv, float *rgb, float *slope_right,
+                       float *slope_bottom);
+
 /* Sampler::Get1D / Get2D of the build's Halton sampler evaluated on the device:
  * out[2*i..] = sample of (seed[i], index[i], dim[i]); is2d selects Get2D. */
 int rgk_sampler_eval(uint32_t n, const uint32_t *seed, const uint32_t *index,

@@ -109,6 +109,7 @@ class Hit(C.Structure):
 EXPORTS = ["rgk_last_error", "rgk_device_count", "rgk_scene_create", "rgk_scene_destroy",
            "rgk_scene_get_info", "rgk_generate_task_list", "rgk_camera_init", "rgk_render_round",
            "rgk_render_round_device", "rgk_trace_closest", "rgk_trace_visibility",
+           "rgk_bxdf_value", "rgk_bxdf_sample", "rgk_texture_sample",
            "rgk_sampler_eval", "rgk_output_normalize", "rgk_output_write_exr", "rgk_float_to_half",
            "rgk_accum_create", "rgk_accum_destroy", "rgk_accum_clear", "rgk_accum_rgb", "rgk_accum_count",
            "rgk_accum_download", "rgk_accum_upload", "rgk_accum_save", "rgk_accum_load",
@@ -134,6 +135,9 @@ def _bind(lib):
                                       _p(Counters)]
     lib.rgk_trace_visibility.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                          C.c_void_p, _p(Counters)]
+    lib.rgk_bxdf_value.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.rgk_bxdf_sample.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.rgk_texture_sample.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rgk_sampler_eval.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                      C.c_void_p]
     lib.rgk_output_normalize.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p, _p(C.c_float)]

@@ -53,6 +53,174 @@ def strip_json_comments(text):
     return "".join(out)
 
 
+class _JsonReader:
+    """The grammar of the reader the reference vendors and calls (external/jsoncpp.cpp `Json::Reader`, src/config.cpp:266-272:
+    comments allowed, root not strict): standard JSON plus // and /* */ comments between tokens and jsoncpp's number token
+    `-?digits[.digits][(e|E)[+-]digits]` -- which takes leading zeros (`000.0` in scenes/conference.json) that Python's json
+    module rejects.  Integers without '.', 'e', 'E' stay integers; everything else is a double.  Trailing content after the
+    root value is ignored, as jsoncpp's old Reader ignores it."""
+
+    def __init__(self, text):
+        self.t, self.i, self.n = text, 0, len(text)
+
+    def fail(self, msg):
+        line = self.t.count("\n", 0, self.i) + 1
+        raise ConfigFileException(f"Failed to parse JSON contents: line {line}: {msg}")
+
+    def skip(self):
+        t, n = self.t, self.n
+        while self.i < n:
+            c = t[self.i]
+            if c in " \t\r\n":
+                self.i += 1
+            elif c == "/" and self.i + 1 < n and t[self.i + 1] == "/":
+                j = t.find("\n", self.i)
+                self.i = n if j < 0 else j + 1
+            elif c == "/" and self.i + 1 < n and t[self.i + 1] == "*":
+                j = t.find("*/", self.i + 2)
+                if j < 0:
+                    self.fail("unterminated comment")
+                self.i = j + 2
+            else:
+                break
+
+    def value(self):
+        self.skip()
+        if self.i >= self.n:
+            self.fail("unexpected end of input")
+        c = self.t[self.i]
+        if c == "{":
+            return self.obj()
+        if c == "[":
+            return self.arr()
+        if c == '"':
+            return self.string()
+        if c == "-" or c.isdigit():
+            return self.number()
+        for word, val in (("true", True), ("false", False), ("null", None)):
+            if self.t.startswith(word, self.i):
+                self.i += len(word)
+                return val
+        self.fail("Syntax error: value, object or array expected.")
+
+    def number(self):
+        t, n, j = self.t, self.n, self.i
+        if t[j] == "-":
+            j += 1
+        while j < n and t[j].isdigit():
+            j += 1
+        if j < n and t[j] == ".":
+            j += 1
+            while j < n and t[j].isdigit():
+                j += 1
+        if j < n and t[j] in "eE":
+            j += 1
+            if j < n and t[j] in "+-":
+                j += 1
+            while j < n and t[j].isdigit():
+                j += 1
+        tok = t[self.i:j]
+        self.i = j
+        try:
+            if any(ch in tok for ch in ".eE"):
+                return float(tok)
+            v = int(tok)
+            return v if -2 ** 63 <= v <= 2 ** 64 - 1 else float(tok)
+        except ValueError:
+            self.fail(f"'{tok}' is not a number.")
+
+    def string(self):
+        t, n = self.t, self.n
+        self.i += 1
+        out = []
+        esc = {'"': '"', "\\": "\\", "/": "/", "b": "\b", "f": "\f", "n": "\n", "r": "\r", "t": "\t"}
+        while True:
+            if self.i >= n:
+                self.fail("unterminated string")
+            c = t[self.i]
+            self.i += 1
+            if c == '"':
+                return "".join(out)
+            if c != "\\":
+                out.append(c)
+                continue
+            if self.i >= n:
+                self.fail("Empty escape sequence in string")
+            e = t[self.i]
+            self.i += 1
+            if e in esc:
+                out.append(esc[e])
+            elif e == "u":
+                cp = self.hex4()
+                if 0xD800 <= cp <= 0xDBFF and t.startswith("\\u", self.i):
+                    self.i += 2
+                    lo = self.hex4()
+                    cp = 0x10000 + ((cp & 0x3FF) << 10) + (lo & 0x3FF)
+                out.append(chr(cp))
+            else:
+                self.fail("Bad escape sequence in string")
+
+    def hex4(self):
+        h = self.t[self.i:self.i + 4]
+        if len(h) != 4 or any(ch not in "0123456789abcdefABCDEF" for ch in h):
+            self.fail("Bad unicode escape sequence in string")
+        self.i += 4
+        return int(h, 16)
+
+    def arr(self):
+        self.i += 1
+        out = []
+        self.skip()
+        if self.i < self.n and self.t[self.i] == "]":
+            self.i += 1
+            return out
+        while True:
+            out.append(self.value())
+            self.skip()
+            if self.i >= self.n:
+                self.fail("Missing ',' or ']' in array declaration")
+            c = self.t[self.i]
+            self.i += 1
+            if c == "]":
+                return out
+            if c != ",":
+                self.fail("Missing ',' or ']' in array declaration")
+
+    def obj(self):
+        self.i += 1
+        out = {}
+        while True:
+            self.skip()
+            if self.i >= self.n:
+                self.fail("Missing '}' or object member name")
+            c = self.t[self.i]
+            if c == "}" and not out:
+                self.i += 1
+                return out
+            if c != '"':
+                self.fail("Missing '}' or object member name")
+            k = self.string()
+            self.skip()
+            if self.i >= self.n or self.t[self.i] != ":":
+                self.fail("Missing ':' after object member name")
+            self.i += 1
+            out[k] = self.value()
+            self.skip()
+            if self.i >= self.n:
+                self.fail("Missing ',' or '}' in object declaration")
+            c = self.t[self.i]
+            self.i += 1
+            if c == "}":
+                return out
+            if c != ",":
+                self.fail("Missing ',' or '}' in object declaration")
+
+
+def parse_json(text):
+    """Parse a config file's text the way the reference's vendored jsoncpp reads it (see _JsonReader)."""
+    return _JsonReader(text).value()
+
+
 def _vec3(v, what):
     if isinstance(v, (list, tuple)):
         if len(v) != 3 or not all(isinstance(x, (int, float)) and not isinstance(x, bool) for x in v):
@@ -155,10 +323,7 @@ class Config:
                 text = open(path).read()
             except OSError:
                 raise ConfigFileException("Failed to open file: " + path)
-            try:
-                root = json.loads(strip_json_comments(text))
-            except json.JSONDecodeError as e:
-                raise ConfigFileException("Failed to parse JSON contents: " + str(e))
+            root = parse_json(text)
         else:
             root = json.loads(json.dumps(root))
         if overrides:

@@ -366,6 +366,8 @@ struct rgk_scene {
     DevBuf<float4> ltc;
     DevBuf<DevScene> self;    // device-resident copy of `dev` (DevScene::self)
     DevBuf<uint32_t> generic; // queue indices left to the generic-BxDF shade launch
+    DevBuf<TexRef> texrefs;   // one TexRef per descriptor texture (rgk_texture_sample)
+    uint32_t n_textures = 0, n_materials = 0;
     DevBuf<DevHaltonDim> hdims;
     DevBuf<uint16_t> hperm;
     // workspace
@@ -387,7 +389,7 @@ struct rgk_scene {
         if (h_counters) (void)hipHostFree(h_counters);
         nodes.release(); tris.release(); tri_shade.release(); materials.release(); texels8.release(); luts.release();
         texels.release(); pointlights.release(); areal.release(); areal_tris.release(); ltc.release(); self.release(); ovf.release();
-        hdims.release(); hperm.release();
+        hdims.release(); hperm.release(); texrefs.release();
         for (int i = 0; i < 2; i++) { rayA[i].release(); rayB[i].release(); }
         hit.release(); thr.release(); tot.release(); shA.release(); shB.release(); shC.release(); pixsum.release();
         light.release(); generic.release(); htab.release(); lstart.release(); lv.release(); term.release(); vfin.release(); vemit.release();
@@ -533,6 +535,22 @@ int validate_desc(const rgk_scene_desc* d) {
 
 } // namespace
 
+namespace {
+// host arrays -> device scratch, one call
+template <typename T>
+int up(DevBuf<T>& b, const T* src, size_t count) {
+    int rc = b.alloc(count);
+    if (rc) return rc;
+    if (hipMemcpy(b.p, src, count * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return fail(RGK_ERR_DEVICE, "hipMemcpy H2D failed");
+    return 0;
+}
+template <typename T>
+int down(T* dst, const DevBuf<T>& b, size_t count) {
+    if (hipMemcpy(dst, b.p, count * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) return fail(RGK_ERR_DEVICE, "hipMemcpy D2H failed");
+    return 0;
+}
+} // namespace
+
 extern "C" {
 
 const char* rgk_last_error(void) { return g_err.c_str(); }
@@ -543,11 +561,36 @@ int rgk_device_count(void) {
     return n;
 }
 
+// RGK_DEBUG_DESC=1: one line per table of the descriptor with an FNV-1a digest of its bytes, on stderr -- lets a host binding
+// be checked against a known-good one ("did my flattening hand over the same scene?") without a debugger.
+static void debug_desc(const rgk_scene_desc* d) {
+    auto h = [](const void* p, size_t n) { uint64_t x = 1469598103934665603ull; const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; p && i < n; i++) { x ^= b[i]; x *= 1099511628211ull; } return (unsigned long long)x; };
+    std::fprintf(stderr, "[rgk desc] vertices %u %016llx normals %016llx tangents %016llx texcoords %016llx\n", d->n_vertices, h(d->vertices, 12ull * d->n_vertices),
+                 h(d->normals, 12ull * d->n_vertices), h(d->tangents, 12ull * d->n_vertices), h(d->texcoords, 8ull * d->n_vertices));
+    std::fprintf(stderr, "[rgk desc] triangles %u idx %016llx mat %016llx\n", d->n_triangles, h(d->tri_indices, 12ull * d->n_triangles), h(d->tri_material, 4ull * d->n_triangles));
+    for (uint32_t i = 0; i < d->n_materials; i++) {
+        const rgk_material& m = d->materials[i];
+        std::fprintf(stderr, "[rgk desc] material %u kind %u flags %u emission %g %g %g rough %.9g ior %.9g amount %.9g tex %d %d %d mix %d %d\n", i, m.kind, m.flags, m.emission[0], m.emission[1],
+                     m.emission[2], m.roughness, m.ior, m.amount, m.tex_diffuse, m.tex_color, m.tex_bump, m.mix_m1, m.mix_m2);
+    }
+    for (uint32_t i = 0; i < d->n_textures; i++) {
+        const rgk_texture& t = d->textures[i];
+        const size_t n = (size_t)t.width * t.height;
+        std::fprintf(stderr, "[rgk desc] texture %u kind %u %ux%u color %.9g %.9g %.9g texels %016llx\n", i, t.kind, t.width, t.height, t.color[0], t.color[1], t.color[2],
+                     t.kind == RGK_TEX_RGB32F ? h(t.texels, 12 * n) : (t.kind == RGK_TEX_RGB8 ? h(t.texels8, 3 * n) ^ h(t.lut, 1024) : 0ull));
+    }
+    std::fprintf(stderr, "[rgk desc] pointlights %u %016llx areal %u offsets %016llx tris %016llx\n", d->n_pointlights, h(d->pointlights, sizeof(rgk_pointlight) * (size_t)d->n_pointlights),
+                 d->n_areal_lights, h(d->areal_offsets, 4ull * (d->n_areal_lights + 1)), h(d->areal_tris, d->n_areal_lights ? 4ull * d->areal_offsets[d->n_areal_lights] : 0));
+    std::fprintf(stderr, "[rgk desc] sky mode %u color %.9g %.9g %.9g intensity %.9g rotate %.9g tex %d ltc %016llx %016llx\n", d->sky_mode, d->sky_color[0], d->sky_color[1], d->sky_color[2],
+                 d->sky_intensity, d->sky_rotate, d->sky_texture, h(d->ltc_ggx, 4096 * 20), h(d->ltc_beckmann, 4096 * 20));
+}
+
 int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
     if (!out) return fail(RGK_ERR_INVALID, "null output pointer");
     *out = nullptr;
     int rc = validate_desc(d);
     if (rc) return rc;
+    if (std::getenv("RGK_DEBUG_DESC")) debug_desc(d);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(RGK_ERR_NO_DEVICE, "no HIP device visible");
     if (device < 0 || device >= ndev) return fail(RGK_ERR_INVALID, "device %d out of range (%d visible)", device, ndev);
@@ -786,6 +829,8 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
     build_halton(hd, hp);
 
     // ---- upload
+    s->n_textures = d->n_textures; s->n_materials = d->n_materials;
+    if ((rc = s->texrefs.upload(trefs))) return rc;
     if ((rc = s->nodes.upload(qb.out)) || (rc = s->tris.upload(leaf_recs)) || (rc = s->tri_shade.upload(tsh)) ||
         (rc = s->materials.upload(mats)) || (rc = s->texels.upload(pool)) || (rc = s->texels8.upload(pool8)) ||
         (rc = s->luts.upload(luts)) || (rc = s->pointlights.upload(pls)) || (rc = s->areal.upload(als)) ||
@@ -1184,6 +1229,56 @@ int rgk_trace_visibility(rgk_scene* s, uint32_t n, const float* a, const float* 
         counters->shadow_node_visits = h[2]; counters->shadow_tri_tests = h[3]; counters->shadow_rays = n;
     }
     return RGK_OK;
+}
+
+int rgk_bxdf_value(rgk_scene* s, uint32_t n, uint32_t route, const uint32_t* mat, const float* Vi, const float* Vr, const float* uv, float* out_rgb) {
+    if (!s || (n && (!mat || !Vi || !Vr || !uv || !out_rgb))) return fail(RGK_ERR_INVALID, "null argument");
+    if (n == 0) return RGK_OK;
+    for (uint32_t i = 0; i < n; i++) if (mat[i] >= s->n_materials) return fail(RGK_ERR_INVALID, "material index out of range");
+    HIPCHK(hipSetDevice(s->device));
+    DevBuf<uint32_t> dm; DevBuf<float> dvi, dvr, duv, dout;
+    int rc;
+    if (!(rc = up(dm, mat, n)) && !(rc = up(dvi, Vi, (size_t)3 * n)) && !(rc = up(dvr, Vr, (size_t)3 * n)) && !(rc = up(duv, uv, (size_t)2 * n)) && !(rc = dout.alloc((size_t)3 * n))) {
+        rgk_launch_bxdf_value(s->stream, s->dev, n, route, dm.p, dvi.p, dvr.p, duv.p, dout.p);
+        if (hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(RGK_ERR_DEVICE, "bxdf value kernel failed");
+        else rc = down(out_rgb, dout, (size_t)3 * n);
+    }
+    dm.release(); dvi.release(); dvr.release(); duv.release(); dout.release();
+    return rc;
+}
+
+int rgk_bxdf_sample(rgk_scene* s, uint32_t n, uint32_t route, const uint32_t* mat, const float* Vi, const float* uv, const float* u, float* out_dir,
+                    float* out_weight, uint8_t* may_leak) {
+    if (!s || (n && (!mat || !Vi || !uv || !u || !out_dir || !out_weight || !may_leak))) return fail(RGK_ERR_INVALID, "null argument");
+    if (n == 0) return RGK_OK;
+    for (uint32_t i = 0; i < n; i++) if (mat[i] >= s->n_materials) return fail(RGK_ERR_INVALID, "material index out of range");
+    HIPCHK(hipSetDevice(s->device));
+    DevBuf<uint32_t> dm; DevBuf<float> dvi, duv, du, dd, dw; DevBuf<uint8_t> dl;
+    int rc;
+    if (!(rc = up(dm, mat, n)) && !(rc = up(dvi, Vi, (size_t)3 * n)) && !(rc = up(duv, uv, (size_t)2 * n)) && !(rc = up(du, u, (size_t)2 * n)) &&
+        !(rc = dd.alloc((size_t)3 * n)) && !(rc = dw.alloc((size_t)3 * n)) && !(rc = dl.alloc(n))) {
+        rgk_launch_bxdf_sample(s->stream, s->dev, n, route, dm.p, dvi.p, duv.p, du.p, dd.p, dw.p, dl.p);
+        if (hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(RGK_ERR_DEVICE, "bxdf sample kernel failed");
+        else if (!(rc = down(out_dir, dd, (size_t)3 * n)) && !(rc = down(out_weight, dw, (size_t)3 * n))) rc = down(may_leak, dl, n);
+    }
+    dm.release(); dvi.release(); duv.release(); du.release(); dd.release(); dw.release(); dl.release();
+    return rc;
+}
+
+int rgk_texture_sample(rgk_scene* s, uint32_t n, const int32_t* tex, const float* uv, float* rgb, float* slope_right, float* slope_bottom) {
+    if (!s || (n && (!tex || !uv || !rgb || !slope_right || !slope_bottom))) return fail(RGK_ERR_INVALID, "null argument");
+    if (n == 0) return RGK_OK;
+    for (uint32_t i = 0; i < n; i++) if (tex[i] >= (int32_t)s->n_textures) return fail(RGK_ERR_INVALID, "texture index out of range");
+    HIPCHK(hipSetDevice(s->device));
+    DevBuf<int32_t> dt; DevBuf<float> duv, drgb, dr, db;
+    int rc;
+    if (!(rc = up(dt, tex, n)) && !(rc = up(duv, uv, (size_t)2 * n)) && !(rc = drgb.alloc((size_t)3 * n)) && !(rc = dr.alloc(n)) && !(rc = db.alloc(n))) {
+        rgk_launch_texture_sample(s->stream, s->dev, n, s->texrefs.p, dt.p, duv.p, drgb.p, dr.p, db.p);
+        if (hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(RGK_ERR_DEVICE, "texture sample kernel failed");
+        else if (!(rc = down(rgb, drgb, (size_t)3 * n)) && !(rc = down(slope_right, dr, n))) rc = down(slope_bottom, db, n);
+    }
+    dt.release(); duv.release(); drgb.release(); dr.release(); db.release();
+    return rc;
 }
 
 int rgk_sampler_eval(uint32_t n, const uint32_t* seed, const uint32_t* index, const uint32_t* dim, int is2d, float* out) {

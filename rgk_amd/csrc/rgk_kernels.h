@@ -88,3 +88,8 @@ void rgk_launch_pack_visibility(hipStream_t st, const DevScene& sc, uint32_t n, 
 void rgk_launch_unpack_hits(hipStream_t st, uint32_t n, const float4* hit, rgk_hit* out);
 void rgk_launch_sampler_eval(hipStream_t st, const DevScene& sc, uint32_t n, const uint32_t* seed, const uint32_t* index,
                              const uint32_t* dim, int is2d, float* out);
+
+void rgk_launch_bxdf_value(hipStream_t st, const DevScene& sc, uint32_t n, uint32_t route, const uint32_t* mat, const float* Vi, const float* Vr, const float* uv, float* out);
+void rgk_launch_bxdf_sample(hipStream_t st, const DevScene& sc, uint32_t n, uint32_t route, const uint32_t* mat, const float* Vi, const float* uv, const float* u,
+                            float* out_dir, float* out_w, uint8_t* leak);
+void rgk_launch_texture_sample(hipStream_t st, const DevScene& sc, uint32_t n, const TexRef* refs, const int32_t* tex, const float* uv, float* rgb, float* sr, float* sb);

@@ -376,6 +376,71 @@ __global__ void k_sampler_eval(const DevScene sc, uint32_t n, const uint32_t* se
     }
 }
 
+// ------------------------------------------------------------------ unit-level seams: BxDF::value / sample, texture lookups
+// route 0: the generic code (bxdf_value / bxdf_sample: every material kind, mixes included);
+// route 1: what k_shade runs for diffuse / LTC materials (mat_prepare + mat_value / mat_sample with the shared fetches), generic otherwise.
+__global__ __launch_bounds__(256) void k_bxdf_value(const DevScene sc, uint32_t n, uint32_t route, const uint32_t* __restrict__ mat, const float* __restrict__ Vi,
+                                                    const float* __restrict__ Vr, const float* __restrict__ uv, float* __restrict__ out) {
+    lut_lds_fill(sc);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const f3 vi = mk3(Vi[3 * i], Vi[3 * i + 1], Vi[3 * i + 2]), vr = mk3(Vr[3 * i], Vr[3 * i + 1], Vr[3 * i + 2]);
+        const float2 t = make_float2(uv[2 * i], uv[2 * i + 1]);
+        f3 v;
+        const DevMaterial m = mat_load(sc, mat[i]);
+        if (route == 1u && mat_is_fast(m.kind)) {
+            MatPrep mp;
+            mat_prepare(sc, m, t, vr, false, mp);
+            v = mat_value<false>(sc, (int)mat[i], m, mp, vi, vr, t);
+        } else v = bxdf_value(sc, (int)mat[i], vi, vr, t);
+        out[3 * i] = v.x; out[3 * i + 1] = v.y; out[3 * i + 2] = v.z;
+    }
+}
+__global__ __launch_bounds__(256) void k_bxdf_sample(const DevScene sc, uint32_t n, uint32_t route, const uint32_t* __restrict__ mat, const float* __restrict__ Vi,
+                                                     const float* __restrict__ uv, const float* __restrict__ u, float* __restrict__ out_dir,
+                                                     float* __restrict__ out_w, uint8_t* __restrict__ leak) {
+    lut_lds_fill(sc);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const f3 vi = mk3(Vi[3 * i], Vi[3 * i + 1], Vi[3 * i + 2]);
+        const float2 t = make_float2(uv[2 * i], uv[2 * i + 1]), uu = make_float2(u[2 * i], u[2 * i + 1]);
+        f3 d, w;
+        bool ml;
+        const DevMaterial m = mat_load(sc, mat[i]);
+        if (route == 1u && mat_is_fast(m.kind)) {
+            MatPrep mp;
+            mat_prepare(sc, m, t, vi, true, mp);
+            mat_sample<false>(sc, (int)mat[i], m, mp, vi, t, uu, d, w, ml);
+        } else bxdf_sample(sc, (int)mat[i], vi, t, uu, d, w, ml);
+        out_dir[3 * i] = d.x; out_dir[3 * i + 1] = d.y; out_dir[3 * i + 2] = d.z;
+        out_w[3 * i] = w.x; out_w[3 * i + 1] = w.y; out_w[3 * i + 2] = w.z;
+        leak[i] = ml ? 1 : 0;
+    }
+}
+__global__ __launch_bounds__(256) void k_texture_sample(const DevScene sc, uint32_t n, const TexRef* __restrict__ refs, const int32_t* __restrict__ tex,
+                                                        const float* __restrict__ uv, float* __restrict__ rgb, float* __restrict__ sr, float* __restrict__ sb) {
+    lut_lds_fill(sc);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        TexRef t;
+        t.kind = RGK_TEXREF_NONE; t.a = t.b = t.c = 0;
+        if (tex[i] >= 0) t = refs[tex[i]];
+        const float2 p = make_float2(uv[2 * i], uv[2 * i + 1]);
+        const f3 c = tex_get(sc, t, p);
+        float r, b;
+        tex_slopes(sc, t, p, r, b);
+        rgb[3 * i] = c.x; rgb[3 * i + 1] = c.y; rgb[3 * i + 2] = c.z;
+        sr[i] = r; sb[i] = b;
+    }
+}
+void rgk_launch_bxdf_value(hipStream_t st, const DevScene& sc, uint32_t n, uint32_t route, const uint32_t* mat, const float* Vi, const float* Vr, const float* uv, float* out) {
+    k_bxdf_value<<<(n + 255) / 256, 256, RGK_LDS_SHADE_BYTES, st>>>(sc, n, route, mat, Vi, Vr, uv, out);
+}
+void rgk_launch_bxdf_sample(hipStream_t st, const DevScene& sc, uint32_t n, uint32_t route, const uint32_t* mat, const float* Vi, const float* uv, const float* u,
+                            float* out_dir, float* out_w, uint8_t* leak) {
+    k_bxdf_sample<<<(n + 255) / 256, 256, RGK_LDS_SHADE_BYTES, st>>>(sc, n, route, mat, Vi, uv, u, out_dir, out_w, leak);
+}
+void rgk_launch_texture_sample(hipStream_t st, const DevScene& sc, uint32_t n, const TexRef* refs, const int32_t* tex, const float* uv, float* rgb, float* sr, float* sb) {
+    k_texture_sample<<<(n + 255) / 256, 256, RGK_LDS_SHADE_BYTES, st>>>(sc, n, refs, tex, uv, rgb, sr, sb);
+}
+
 // ------------------------------------------------------------------ launch wrappers (host)
 // Upper bound on the length of the queues the next launches will consume (the host reads a queue counter back every
 // few bounces of a deep path loop): a 40-bounce round ends in dozens of launches over a few hundred rays, and a

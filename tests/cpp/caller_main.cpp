@@ -100,7 +100,8 @@ int main(int argc, char** argv) {
         const uint32_t npl = r.get<uint32_t>();
         for (uint32_t i = 0; i < npl; i++) {
             Light l(Light::FULL_SPHERE);
-            l.pos = glm::vec3(r.get<float>(), r.get<float>(), r.get<float>());
+            const float px = r.get<float>(), py = r.get<float>(), pz = r.get<float>(); // (not as call arguments: their evaluation order is unspecified)
+            l.pos = glm::vec3(px, py, pz);
             const float cr = r.get<float>(), cg = r.get<float>(), cb = r.get<float>();
             l.color = Radiance(cr, cg, cb);
             l.intensity = r.get<float>(); l.size = r.get<float>();

@@ -643,3 +643,100 @@ def test_ragged_tiles_pixel_list(rd, oracle):
         rel = np.linalg.norm(ag - ao) / np.linalg.norm(ao)
         print(f"[ragged {w}x{h}] rel-L2 {rel:.2e}")
         assert rel <= 1e-3
+
+
+# ----------------------------------------------------------------------- unit level: BxDF::value / sample, texture lookups (a11, a12, a14)
+def _unit_dirs(rng, n):
+    """Local-frame directions: mostly the upper hemisphere, some below it, some exactly grazing / along the normal."""
+    v = rng.normal(size=(n, 3)).astype(np.float32)
+    v[:, 2] = np.abs(v[:, 2])
+    v[::11, 2] *= -1.0
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    v[::97] = (0.0, 0.0, 1.0)
+    return np.ascontiguousarray(v.astype(np.float32))
+
+
+def test_bxdf_value_and_sample_unit_level(rd, oracle, product_lib):
+    """BxDF::value / BxDF::sample of every material kind on a direction x uv x sample grid, HIP (both routes: the generic
+    code and the shading kernel's shared-fetch route) against the oracle's restatement of src/bxdf/bxdf.cpp + src/LTC/ltc.cpp.
+    The LTC closed forms of the device keep the oracle's operation order, so values are bit-identical except through libm
+    (acosf, sinf, cosf, sqrtf are the same IEEE results; acosf/sinf/cosf differ by <= 2 ulp between glibc and ocml)."""
+    sb = material_zoo()
+    # + textured LTC materials with every roughness the table's alpha axis sees, bump-free (textures are covered below)
+    for k, r in enumerate((0.02, 0.0995, 0.3, 0.6, 1.0)):
+        m = sb.new_material(f"ltc{k}", capi.BXDF_LTC_GGX_DIFFUSE if k % 2 else capi.BXDF_LTC_BECKMANN_DIFFUSE)
+        m["tex_diffuse"] = sb.create_solid_texture((0.6, 0.5, 0.4)); m["tex_color"] = sb.create_solid_texture((0.3, 0.3, 0.25)); m["roughness"] = r
+        sb.register_material(m)
+    desc = sb.to_desc()
+    g, o = rd.Scene(desc), oracle.OracleScene(desc)
+    L = oracle.lib()
+    rng = np.random.default_rng(21)
+    n_mat, n = len(sb.materials), 4000
+    mat = (np.arange(n) % n_mat).astype(np.uint32)
+    Vi, Vr = _unit_dirs(rng, n), _unit_dirs(rng, n)
+    # delta lobes need exactly mirrored / refracted pairs to be non-zero: give a share of the inputs Vr = reflect(Vi)
+    Vr[::3] = Vi[::3] * np.array([-1, -1, 1], np.float32)
+    uv = rng.uniform(-1, 2, (n, 2)).astype(np.float32)
+    u = rng.uniform(0, 1, (n, 2)).astype(np.float32)
+    ref_v = np.zeros((n, 3), np.float32); ref_d = np.zeros((n, 3), np.float32); ref_w = np.zeros((n, 3), np.float32); ref_l = np.zeros(n, np.int32)
+    for i in range(n):
+        L.orc_bxdf_value(o.h, int(mat[i]), Vi[i].ctypes.data, Vr[i].ctypes.data, uv[i].ctypes.data, ref_v[i].ctypes.data)
+        ml = C.c_int(0)
+        L.orc_bxdf_sample(o.h, int(mat[i]), Vi[i].ctypes.data, uv[i].ctypes.data, u[i].ctypes.data, ref_d[i].ctypes.data, ref_w[i].ctypes.data, C.byref(ml))
+        ref_l[i] = ml.value
+    for route in (0, 1):
+        val = np.zeros((n, 3), np.float32); d = np.zeros((n, 3), np.float32); w = np.zeros((n, 3), np.float32); leak = np.zeros(n, np.uint8)
+        assert product_lib.rgk_bxdf_value(g.h, n, route, mat.ctypes.data, Vi.ctypes.data, Vr.ctypes.data, uv.ctypes.data, val.ctypes.data) == 0
+        assert product_lib.rgk_bxdf_sample(g.h, n, route, mat.ctypes.data, Vi.ctypes.data, uv.ctypes.data, u.ctypes.data, d.ctypes.data, w.ctypes.data, leak.ctypes.data) == 0
+        both_nan = np.isnan(val) & np.isnan(ref_v)          # Q6: view exactly along N -> singular LTC frame -> NaN on both sides
+        ev = np.abs(val - ref_v)[~both_nan]; sv = np.maximum(np.abs(ref_v), 1e-6)[~both_nan]
+        assert np.array_equal(np.isnan(val), np.isnan(ref_v))
+        rel_v = float((ev / sv).max())
+        exact_v = float((val.view(np.uint32) == ref_v.view(np.uint32)).all(axis=1).mean())
+        ok = ~np.isnan(ref_d).any(axis=1)
+        err_d = float(np.abs(d[ok] - ref_d[ok]).max())
+        exact_d = float((d.view(np.uint32) == ref_d.view(np.uint32)).all(axis=1).mean())
+        record_parity(f"test_bxdf_value_and_sample_unit_level:route{route}", n=n, value_max_rel=rel_v, value_bit_identical=exact_v,
+                      sample_dir_max_abs=err_d, sample_dir_bit_identical=exact_d, nonzero_values=float((ref_v.max(axis=1) > 0).mean()))
+        assert rel_v <= 2e-4 and err_d <= 2e-5        # libm only: acosf (the LTC table angle: a 1-ulp theta moves the bilinear weights), sinf / cosf (disc sample)
+        assert np.array_equal(w.view(np.uint32), ref_w.view(np.uint32)) or np.abs(w - ref_w).max() <= 1e-7
+        assert np.array_equal(leak.astype(np.int32), ref_l)
+    assert (ref_v.max(axis=1) > 0).mean() > 0.3 and ref_l.any()
+    assert product_lib.rgk_bxdf_value(g.h, 1, 0, np.array([999], np.uint32).ctypes.data, Vi.ctypes.data, Vr.ctypes.data, uv.ctypes.data, val.ctypes.data) == -1
+
+
+def test_texture_lookup_unit_level(rd, oracle, product_lib):
+    """GetPixelInterpolated / GetSlopeRight / GetSlopeBottom (src/texture.cpp:35-102): solid, empty, float and 8-bit textures
+    (the PNG of rubiks-bump and one of the shipped Sponza JPGs as decoded bytes), uv inside, outside (repeat), on texel
+    centres and on the wrap seam: integer / float arithmetic only, so HIP and oracle must agree bit for bit."""
+    from rgk_amd.proxy import shipped_sponza_textures
+    sb = SceneBuilder()
+    rng = np.random.default_rng(22)
+    ids = [sb.create_solid_texture((0.2, 0.5, 0.9)), -1,
+           sb.add_image_texture("f32", rng.random((37, 53, 3)).astype(np.float32) * 3.0),
+           sb.add_image_texture8("u8", rng.integers(0, 256, (29, 64, 3), dtype=np.uint8))]
+    jpg = shipped_sponza_textures().get("KAMEN.JPG")
+    if jpg is not None:
+        ids.append(sb.add_image_texture8("kamen", np.ascontiguousarray(jpg[::-1])))
+    m = sb.new_material("m", capi.BXDF_DIFFUSE); m["tex_diffuse"] = ids[0]; sb.register_material(m)
+    sb.add_primitive("cube", np.eye(4, dtype=np.float32), "m")
+    desc = sb.to_desc()
+    g, o = rd.Scene(desc), oracle.OracleScene(desc)
+    L = oracle.lib()
+    n = 6000
+    tex = np.array([ids[i % len(ids)] for i in range(n)], dtype=np.int32)
+    uv = rng.uniform(-2, 3, (n, 2)).astype(np.float32)
+    uv[::7] = np.round(uv[::7] * 8) / 8                      # seams and exact fractions
+    uv[::13] = (np.floor(uv[::13] * 53) + 0.5) / 53          # texel centres of the 53-wide image
+    rgb = np.zeros((n, 3), np.float32); sr = np.zeros(n, np.float32); sbm = np.zeros(n, np.float32)
+    assert product_lib.rgk_texture_sample(g.h, n, tex.ctypes.data, uv.ctypes.data, rgb.ctypes.data, sr.ctypes.data, sbm.ctypes.data) == 0
+    ref = np.zeros((n, 3), np.float32); rr = np.zeros(n, np.float32); rb = np.zeros(n, np.float32)
+    for i in range(n):
+        a, b = C.c_float(0), C.c_float(0)
+        L.orc_texture_sample(o.h, int(tex[i]), uv[i].ctypes.data, ref[i].ctypes.data, C.byref(a), C.byref(b))
+        rr[i], rb[i] = a.value, b.value
+    record_parity("test_texture_lookup_unit_level", n=n, rgb_bit_identical=float((rgb.view(np.uint32) == ref.view(np.uint32)).all(axis=1).mean()),
+                  slopes_bit_identical=float(((sr.view(np.uint32) == rr.view(np.uint32)) & (sbm.view(np.uint32) == rb.view(np.uint32))).mean()))
+    assert np.array_equal(rgb.view(np.uint32), ref.view(np.uint32))
+    assert np.array_equal(sr.view(np.uint32), rr.view(np.uint32)) and np.array_equal(sbm.view(np.uint32), rb.view(np.uint32))
+    assert product_lib.rgk_texture_sample(g.h, 1, np.array([77], np.int32).ctypes.data, uv.ctypes.data, rgb.ctypes.data, sr.ctypes.data, sbm.ctypes.data) == -1

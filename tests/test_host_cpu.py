@@ -10,7 +10,9 @@ import numpy as np
 import pytest
 
 from rgk_amd import capi
-from rgk_amd.config import Config, ConfigFileException, strip_json_comments
+
+REF_DIR = os.environ.get("RGK_REFERENCE", "/root/reference")
+from rgk_amd.config import Config, ConfigFileException, parse_json, strip_json_comments
 from rgk_amd.scene import SceneBuilder, primitive_data
 
 from conftest import ROOT
@@ -164,6 +166,46 @@ def test_json_comments_and_defaults(tmp_path):
     assert sb.pointlights[0]["color"] == (1.0, 1.0, 1.0)
 
 
+def _canonical(v):
+    """The canonical text form oracle/ref_jsoncpp_main.cpp prints for a parsed JSON tree."""
+    if v is None:
+        return "null"
+    if isinstance(v, bool):
+        return "true" if v else "false"
+    if isinstance(v, int):
+        return ("i%d" % v) if v <= 2 ** 63 - 1 else ("u%d" % v)
+    if isinstance(v, float):
+        return "r%s" % ("%.17g" % v)
+    if isinstance(v, str):
+        return '"' + "".join("\\" + c if c in '"\\' else ("\\u%04x" % ord(c) if ord(c) < 0x20 else c) for c in v) + '"'
+    if isinstance(v, list):
+        return "[" + ",".join(_canonical(x) for x in v) + "]"
+    return "{" + ",".join('"%s":%s' % (k, _canonical(v[k])) for k in sorted(v)) + "}"
+
+
+def test_json_front_end_parses_every_shipped_scene_like_the_references_jsoncpp():
+    """f1 pinned: the reference's own JSON reader (external/jsoncpp.cpp, compiled where it lies into oracle/_ref/jsoncpp_ref,
+    called as src/config.cpp:266-272 calls it) against rgk_amd.config's comment stripping + json parse, on all the scene
+    files the reference ships: identical trees -- keys, nesting, strings, integer-vs-real typing, every number to 17 digits."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "jsoncpp_ref")
+    scenes = os.path.join(REF_DIR, "scenes")
+    if not (os.path.exists(exe) and os.path.isdir(scenes)):
+        pytest.skip("oracle/_ref/jsoncpp_ref or the reference's scenes are absent on this box")
+    files = sorted(os.path.join(d, f) for d, _, fs in os.walk(scenes) for f in fs if f.endswith(".json") or f.endswith(".rtc"))
+    assert len(files) >= 39
+    out = subprocess.run([exe] + files, capture_output=True, text=True, check=True).stdout.strip().split("\n")
+    assert len(out) == len(files)
+    n_comments = 0
+    for line, path in zip(out, files):
+        p, tree = line.split("\t", 1)
+        assert p == path and tree != "ERROR", path
+        text = open(path).read()
+        n_comments += ("//" in text) or ("/*" in text)
+        mine = _canonical(parse_json(text))
+        assert mine == tree, path
+    assert n_comments >= 5   # the comment syntax is exercised (scenes/cornell-box.json and others carry comments)
+
+
 def test_config_errors(tmp_path):
     def cfg(d):
         p = tmp_path / "e.json"
@@ -186,6 +228,10 @@ def test_config_errors(tmp_path):
     with pytest.raises(ConfigFileException, match="neither"):
         c.build_scene()
     assert strip_json_comments('{"a": "x//y" /* c */ } // t') == '{"a": "x//y"  } '
+    assert parse_json('{"a": "x//y" /* c */, "b": [000.50, -07, 1e2, "\\u00e9\\n"] } // t') == {"a": "x//y", "b": [0.5, -7, 100.0, "\u00e9\n"]}
+    for bad in ('{"a": [1, 2,]}', '{"a" 1}', '{1: 2}', '[1 2]', '"abc'):
+        with pytest.raises(ConfigFileException):
+            parse_json(bad)
 
 
 def test_builtin_primitives_match_reference_shapes():

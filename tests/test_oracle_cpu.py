@@ -41,6 +41,35 @@ def test_halton_fixture_regenerates_from_reference_header():
     assert np.array_equal(np.frombuffer(out, dtype=np.float32).reshape(256, -1).view(np.uint32), z["values"].view(np.uint32))
 
 
+LTC_SHA256 = {  # rgk_amd/data/ltc_<name>.f32: 64 x 64 x {m0, m2, m4, m6, amplitude} float32
+    "ggx": "a7ca69cce519b31231ef769303dd5f19985550642f802b67d3c19752925bed8f",
+    "beckmann": "73bbe6061c8e3f2b75c8aaef25854531b65869cfd5676704b555f8021f5271fb",
+}
+
+
+def test_ltc_tables_are_the_references_and_regenerate_from_its_source():
+    """a12 pinned at the data level: the LTC fit tables both the oracle and the HIP path interpolate are the numeric initialisers
+    of the reference's src/LTC/ltc_ggx.cpp / ltc_beckmann.cpp (tabM, tabAmplitude), rounded to float as mat33::operator
+    glm::mat3() rounds them on every read.  The committed files carry a checksum (always checked); where the reference tree is
+    present they are regenerated from its source text and must come out byte-identical."""
+    import hashlib
+    import importlib.util
+    for name, want in LTC_SHA256.items():
+        blob = open(os.path.join(ROOT, "rgk_amd", "data", f"ltc_{name}.f32"), "rb").read()
+        assert len(blob) == 64 * 64 * 5 * 4 and hashlib.sha256(blob).hexdigest() == want, name
+    ref = os.environ.get("RGK_REFERENCE", "/root/reference")
+    if not os.path.exists(os.path.join(ref, "src", "LTC", "ltc_ggx.cpp")):
+        pytest.skip("reference tree absent on this box: checksum only")
+    spec = importlib.util.spec_from_file_location("extract_ltc_tables", os.path.join(ROOT, "tools", "extract_ltc_tables.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for name in LTC_SHA256:
+        rec = mod.extract(name)
+        assert rec.dtype == np.float32 and rec.shape == (4096, 5)
+        assert rec.tobytes() == open(os.path.join(ROOT, "rgk_amd", "data", f"ltc_{name}.f32"), "rb").read(), name
+        # the oracle reads the same numbers: LTC::get_bilinear at a grid point returns the table entry itself
+
+
 def test_halton_known_values(oracle):
     L = oracle.lib()
     # SURVEY 8(c) probes of the vendored header
