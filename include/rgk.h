@@ -308,6 +308,10 @@ int rgk_bxdf_sample(rgk_scene *scene, uint32_t n, uint32_t route, const uint32_t
 int rgk_texture_sample(rgk_scene *scene, uint32_t n, const int32_t *tex, const float *uv, float *rgb, float *slope_right,
                        float *slope_bottom);
 
+/* The pinned transcendental functions of the path (include/rgk_libm.h) evaluated on the device, for the test that the GPU
+ * and the CPU produce the same bits: fn 0 sin, 1 cos, 2 acos, 3 asin, 4 atan2(a[i], b[i]) (b may be NULL otherwise). */
+int rgk_libm_eval(int fn, uint32_t n, const float *a, const float *b, float *out);
+
 /* Sampler::Get1D / Get2D of the build's Halton sampler evaluated on the device:
  * out[2*i..] = sample of (seed[i], index[i], dim[i]); is2d selects Get2D. */
 int rgk_sampler_eval(uint32_t n, const uint32_t *seed, const uint32_t *index,

@@ -608,8 +608,8 @@ Light Scene::GetRandomLight(vec2 choice_sample, float light_sample, vec2 triangl
 // scene.cpp:748-763
 Radiance Scene::GetSkyboxRay(vec3 direction) const {
     if (skybox_mode == RGK_SKY_COLOR) return Radiance(skybox_color) * Spectrum(skybox_intensity);
-    float alpha = std::asin(direction.y);
-    float beta = -std::atan2(direction.x, direction.z);
+    float alpha = rgk_asinf(direction.y);             // std::asin / std::atan2 in the reference: pinned, include/rgk_libm.h
+    float beta = -rgk_atan2f(direction.x, direction.z);
     beta += skybox_rotate * 0.0174533f;
     float x = beta / (2.0f * PI_F) + 0.5f;
     float y = alpha / PI_F + 0.5f;
@@ -661,7 +661,7 @@ namespace RandomUtils {
 static vec2 Sample2DToDiscUniform(vec2 sample) {
     float r = std::sqrt(sample.x);
     float a = (float)(sample.y * 2.0f * M_PI);
-    return vec2(r * std::sin(a), r * std::cos(a));
+    return vec2(r * rgk_sinf(a), r * rgk_cosf(a)); // std::sin / std::cos in the reference: pinned, include/rgk_libm.h
 }
 static vec3 Sample2DToHemisphereCosine(vec2 sample) {
     vec2 p = Sample2DToDiscUniform(sample);
@@ -680,8 +680,8 @@ static vec3 Sample2DToSphereUniform(vec2 sample) {
     float z = sample.x * 2.0f - 1.0f;
     float a = (float)(sample.y * 6.283185);
     float r = std::sqrt(1 - z * z);
-    float x = r * std::cos(a);
-    float y = r * std::sin(a);
+    float x = r * rgk_cosf(a);
+    float y = r * rgk_sinf(a);
     return vec3(x, y, z);
 }
 static bool DecideAndRescale(float& sample, float probability) {
@@ -1599,6 +1599,20 @@ int orc_texture_sample(void* h, int tex, const float* uv, float* rgb, float* slo
     rgb[0] = c.r; rgb[1] = c.g; rgb[2] = c.b;
     *slope_right = tex < 0 ? 0 : s->textures[tex].GetSlopeRight(vec2(uv[0], uv[1]));
     *slope_bottom = tex < 0 ? 0 : s->textures[tex].GetSlopeBottom(vec2(uv[0], uv[1]));
+    return 0;
+}
+// the pinned transcendental functions (include/rgk_libm.h) for unit tests: fn 0 sin, 1 cos, 2 acos, 3 asin, 4 atan2(a, b)
+int orc_libm(int fn, uint32_t n, const float* a, const float* b, float* out) {
+    for (uint32_t i = 0; i < n; i++) {
+        switch (fn) {
+        case 0: out[i] = rgk_sinf(a[i]); break;
+        case 1: out[i] = rgk_cosf(a[i]); break;
+        case 2: out[i] = rgk_acosf(a[i]); break;
+        case 3: out[i] = rgk_asinf(a[i]); break;
+        case 4: out[i] = rgk_atan2f(a[i], b[i]); break;
+        default: return -1;
+        }
+    }
     return 0;
 }
 // Camera::Camera for unit tests (the oracle's own restatement of src/camera.cpp:7-24)

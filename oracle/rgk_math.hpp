@@ -12,6 +12,8 @@
 #include <cmath>
 #include <cstdint>
 
+#include "../include/rgk_libm.h" // sin / cos / acos / asin / atan2 on the path: pinned definitions shared with the HIP kernels
+
 namespace orc {
 
 struct vec2 {
@@ -57,7 +59,7 @@ inline vec3 normalize(vec3 v) { return v * (1.0f / std::sqrt(dot(v, v))); }
 inline float distance2(vec3 a, vec3 b) { vec3 d = b - a; return dot(d, d); }
 inline float clampf(float x, float lo, float hi) { return std::fmin(std::fmax(x, lo), hi); }
 // glm::angle(x,y) = acos(clamp(dot(x,y), -1, 1))
-inline float angle(vec3 a, vec3 b) { return std::acos(clampf(dot(a, b), -1.0f, 1.0f)); }
+inline float angle(vec3 a, vec3 b) { return rgk_acosf(clampf(dot(a, b), -1.0f, 1.0f)); } // acos pinned: include/rgk_libm.h
 inline vec3 vabs(vec3 v) { return vec3(std::fabs(v.x), std::fabs(v.y), std::fabs(v.z)); }
 // glm::repeat(x) = fract(x) = x - floor(x)
 inline float repeat(float x) { return x - std::floor(x); }
@@ -83,8 +85,8 @@ inline quat inverse(const quat& q) {
 }
 // glm::angleAxis(angle, axis)
 inline quat angleAxis(float a, vec3 axis) {
-    float s = std::sin(a * 0.5f);
-    return quat(std::cos(a * 0.5f), axis.x * s, axis.y * s, axis.z * s);
+    float s = rgk_sinf(a * 0.5f);
+    return quat(rgk_cosf(a * 0.5f), axis.x * s, axis.y * s, axis.z * s);
 }
 
 // column-major 3x3, m[col][row] like glm::mat3

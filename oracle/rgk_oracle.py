@@ -48,6 +48,7 @@ def lib():
         L.orc_bxdf_sample.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, _p(C.c_int)]
         L.orc_texture_sample.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _p(C.c_float), _p(C.c_float)]
+        L.orc_libm.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_camera_init.argtypes = [_p(capi.Camera), capi.f3, capi.f3, capi.f3, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_float]
         L.orc_camera_ray.argtypes = [_p(capi.Camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                      C.c_void_p, C.c_void_p]

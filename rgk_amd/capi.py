@@ -110,7 +110,7 @@ EXPORTS = ["rgk_last_error", "rgk_device_count", "rgk_scene_create", "rgk_scene_
            "rgk_scene_get_info", "rgk_generate_task_list", "rgk_camera_init", "rgk_render_round",
            "rgk_render_round_device", "rgk_trace_closest", "rgk_trace_visibility",
            "rgk_bxdf_value", "rgk_bxdf_sample", "rgk_texture_sample",
-           "rgk_sampler_eval", "rgk_output_normalize", "rgk_output_write_exr", "rgk_float_to_half",
+           "rgk_libm_eval", "rgk_sampler_eval", "rgk_output_normalize", "rgk_output_write_exr", "rgk_float_to_half",
            "rgk_accum_create", "rgk_accum_destroy", "rgk_accum_clear", "rgk_accum_rgb", "rgk_accum_count",
            "rgk_accum_download", "rgk_accum_upload", "rgk_accum_save", "rgk_accum_load",
            "rgk_shard_tiles", "rgk_comm_get_unique_id", "rgk_comm_create", "rgk_comm_destroy", "rgk_accum_reduce"]
@@ -138,6 +138,7 @@ def _bind(lib):
     lib.rgk_bxdf_value.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rgk_bxdf_sample.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rgk_texture_sample.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.rgk_libm_eval.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rgk_sampler_eval.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                      C.c_void_p]
     lib.rgk_output_normalize.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p, _p(C.c_float)]

@@ -3,11 +3,12 @@
 // Each function states the reference function whose RESULT it reproduces.  The code is
 // written for the GPU (registers, float4 records, no virtual dispatch), not transcribed:
 // but every float operation that feeds a result is kept in the reference's evaluation
-// order and the library is built with -ffp-contract=off, so that GPU and CPU agree to
-// the last bit everywhere except inside libm (sinf/cosf/acosf/...), see DESIGN.md.
+// order and the library is built with -ffp-contract=off; sin / cos / acos / asin / atan2 are the pinned
+// definitions of include/rgk_libm.h on both sides -- so GPU and CPU agree to the last bit, see DESIGN.md.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "device_types.h"
+#include "../../include/rgk_libm.h" // sin / cos / acos / asin / atan2: pinned definitions shared with the oracle (bit-identical on CPU and GPU)
 
 #define RGK_PI_F 3.14159265358979323846264338327950288f
 
@@ -70,7 +71,7 @@ __device__ __forceinline__ float len3(f3 v) { return sqrtf(dot3(v, v)); }
 __device__ __forceinline__ f3 norm3(f3 v) { return v * (1.0f / sqrtf(dot3(v, v))); }
 __device__ __forceinline__ float comp(f3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
 __device__ __forceinline__ float max3c(f3 v) { return fmaxf(fmaxf(v.x, v.y), v.z); }
-__device__ __forceinline__ float glm_angle(f3 a, f3 b) { return acosf(fminf(fmaxf(dot3(a, b), -1.0f), 1.0f)); }
+__device__ __forceinline__ float glm_angle(f3 a, f3 b) { return rgk_acosf(fminf(fmaxf(dot3(a, b), -1.0f), 1.0f)); }
 
 struct quatf {
     float w, x, y, z;
@@ -88,8 +89,9 @@ __device__ __forceinline__ quatf qinverse(quatf q) {
     return r;
 }
 __device__ __forceinline__ quatf angle_axis(float a, f3 axis) {
-    float s = sinf(a * 0.5f);
-    quatf r; r.w = cosf(a * 0.5f); r.x = axis.x * s; r.y = axis.y * s; r.z = axis.z * s;
+    float s, c;
+    rgk_sincosf(a * 0.5f, &s, &c);
+    quatf r; r.w = c; r.x = axis.x * s; r.y = axis.y * s; r.z = axis.z * s;
     return r;
 }
 // RotationBetweenVectors, reference src/glm.cpp:3-33
@@ -195,7 +197,9 @@ __device__ __forceinline__ float sample1d_t(const SamplerTab& tb, uint32_t seed,
 __device__ __forceinline__ float2 disc_uniform(float2 s) {
     float r = sqrtf(s.x);
     float a = (float)((double)(s.y * 2.0f) * 3.14159265358979323846);
-    return make_float2(r * sinf(a), r * cosf(a));
+    float sn, cs;
+    rgk_sincosf(a, &sn, &cs);
+    return make_float2(r * sn, r * cs);
 }
 __device__ __forceinline__ f3 hemisphere_cosine_z(float2 s) {
     float2 p = disc_uniform(s);
@@ -211,7 +215,9 @@ __device__ __forceinline__ f3 sphere_uniform(float2 s) {
     float z = s.x * 2.0f - 1.0f;
     float a = (float)((double)s.y * 6.283185);
     float r = sqrtf(1 - z * z);
-    return mk3(r * cosf(a), r * sinf(a), z);
+    float sn, cs;
+    rgk_sincosf(a, &sn, &cs);
+    return mk3(r * cs, r * sn, z);
 }
 __device__ __forceinline__ bool decide_and_rescale(float& sample, float probability) {
     if (probability == 0.0f) return false;
@@ -729,8 +735,8 @@ __device__ __forceinline__ DLight light_from_code(const DevScene& sc, f3 pos, ui
 // Scene::GetSkyboxRay, reference src/scene.cpp:748-763
 __device__ __forceinline__ f3 skybox(const DevScene& sc, f3 direction) {
     if (sc.sky_mode == 0) return mk3(sc.sky_color[0], sc.sky_color[1], sc.sky_color[2]) * mk3(sc.sky_intensity, sc.sky_intensity, sc.sky_intensity);
-    float alpha = asinf(direction.y);
-    float beta = -atan2f(direction.x, direction.z);
+    float alpha = rgk_asinf(direction.y);
+    float beta = -rgk_atan2f(direction.x, direction.z);
     beta += sc.sky_rotate * 0.0174533f;
     float x = beta / (2.0f * RGK_PI_F) + 0.5f;
     float y = alpha / RGK_PI_F + 0.5f;

@@ -1281,6 +1281,22 @@ int rgk_texture_sample(rgk_scene* s, uint32_t n, const int32_t* tex, const float
     return rc;
 }
 
+int rgk_libm_eval(int fn, uint32_t n, const float* a, const float* b, float* out) {
+    if (n && (!a || !out || (fn == 4 && !b))) return fail(RGK_ERR_INVALID, "null argument");
+    if (fn < 0 || fn > 4) return fail(RGK_ERR_INVALID, "unknown function");
+    if (n == 0) return RGK_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(RGK_ERR_NO_DEVICE, "no HIP device visible");
+    DevBuf<float> da, db, dout;
+    int rc;
+    if (!(rc = up(da, a, n)) && !(rc = up(db, b ? b : a, n)) && !(rc = dout.alloc(n))) {
+        rgk_launch_libm_eval(nullptr, fn, n, da.p, db.p, dout.p);
+        rc = down(out, dout, n);
+    }
+    da.release(); db.release(); dout.release();
+    return rc;
+}
+
 int rgk_sampler_eval(uint32_t n, const uint32_t* seed, const uint32_t* index, const uint32_t* dim, int is2d, float* out) {
     if (n && (!seed || !index || !dim || !out)) return fail(RGK_ERR_INVALID, "null argument");
     if (n == 0) return RGK_OK;

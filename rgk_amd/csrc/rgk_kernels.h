@@ -93,3 +93,4 @@ void rgk_launch_bxdf_value(hipStream_t st, const DevScene& sc, uint32_t n, uint3
 void rgk_launch_bxdf_sample(hipStream_t st, const DevScene& sc, uint32_t n, uint32_t route, const uint32_t* mat, const float* Vi, const float* uv, const float* u,
                             float* out_dir, float* out_w, uint8_t* leak);
 void rgk_launch_texture_sample(hipStream_t st, const DevScene& sc, uint32_t n, const TexRef* refs, const int32_t* tex, const float* uv, float* rgb, float* sr, float* sb);
+void rgk_launch_libm_eval(hipStream_t st, int fn, uint32_t n, const float* a, const float* b, float* out);

@@ -430,6 +430,19 @@ __global__ __launch_bounds__(256) void k_texture_sample(const DevScene sc, uint3
         sr[i] = r; sb[i] = b;
     }
 }
+// the pinned transcendental functions (include/rgk_libm.h) evaluated on the device: fn 0 sin, 1 cos, 2 acos, 3 asin, 4 atan2(a, b)
+__global__ void k_libm_eval(int fn, uint32_t n, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float r = 0.f;
+        if (fn == 0) r = rgk_sinf(a[i]);
+        else if (fn == 1) r = rgk_cosf(a[i]);
+        else if (fn == 2) r = rgk_acosf(a[i]);
+        else if (fn == 3) r = rgk_asinf(a[i]);
+        else r = rgk_atan2f(a[i], b[i]);
+        out[i] = r;
+    }
+}
+void rgk_launch_libm_eval(hipStream_t st, int fn, uint32_t n, const float* a, const float* b, float* out) { k_libm_eval<<<(n + 255) / 256, 256, 0, st>>>(fn, n, a, b, out); }
 void rgk_launch_bxdf_value(hipStream_t st, const DevScene& sc, uint32_t n, uint32_t route, const uint32_t* mat, const float* Vi, const float* Vr, const float* uv, float* out) {
     k_bxdf_value<<<(n + 255) / 256, 256, RGK_LDS_SHADE_BYTES, st>>>(sc, n, route, mat, Vi, Vr, uv, out);
 }

@@ -3,10 +3,14 @@ seeded inputs; plus size-independent properties at larger sizes.
 
 Bars: integer / index work bit-exact (sampler bits, triangle ids, sample counts, tile lists);
 float results within the stated tolerance:
-  * closest hit: same triangle except exact/epsilon-band ties (SURVEY H3), and then t, a, b, c bit-equal;
-  * image: per-pixel ||d||2 <= max(1e-3 ||ref||2, 4 clamp / S) for >= 99.9 % of pixels and whole-image
-    relative L2 <= 1e-3 on the duplicate-free Cornell box; on the proxy Sponza, whose
-    coincident surfaces tie-break differently in a BVH than in the kd-tree, relative L2 <= 1e-2.
+  * closest hit: same triangle except epsilon-band ties (SURVEY H3), and then t, a, b, c bit-equal;
+  * image: sin / cos / acos / asin / atan2 are pinned (include/rgk_libm.h: same bits on CPU and GPU) and every other
+    float operation keeps the oracle's order without contraction, so images are bit-identical pixel for pixel except where
+    one path meets an epsilon-band tie the kd-tree and the BVH resolve differently, or where splats are float atomics
+    (reverse > 0).  Gate: per-pixel ||d||2 <= 1e-3 ||ref||2 for >= 99.9 % of pixels and whole-image relative
+    L2 <= 1e-3 -- held on every configuration incl. the benchmark workload at full size; the few-spp small-size proxies
+    of the unclamped Sponza configs allow 5e-3 (one tie path is most of a pixel there).  Every test records what it
+    measured (conftest.record_parity -> the table at the end of the run, gpurun_out/parity_measured.txt).
 """
 import ctypes as C
 import os
@@ -173,9 +177,9 @@ def test_triangle_soup_with_degenerates(rd, oracle):
 # ----------------------------------------------------------------------- scenes the reference ships complete
 REFERENCE_SCENES = {  # name -> (scale, spp, image rel-L2 bound): fixtures made by tools/make_fixtures.py
     "rubiks-bump": (0.15, 16, 1e-3),          # PNG texture + bump map, point light, bumpscale 15
-    "cube3": (0.12, 16, 2e-3),                # 8966 faces, LTC Beckmann, sphere light size 0.4, russian 0.6
-    "box6": (0.1, 16, 1e-2),                  # 17 k triangles with uv, emissive triangles, reverse = 3 (splats: float atomics)
-    "cornell-box-spheres": (0.12, 16, 2e-3),  # LTC Beckmann + dielectric spheres (may_leak), areal lights
+    "cube3": (0.12, 16, 1e-6),                # 8966 faces, LTC Beckmann, sphere light size 0.4, russian 0.6
+    "box6": (0.1, 16, 1e-5),                  # 17 k triangles with uv, emissive triangles, reverse = 3 (splats: float atomics)
+    "cornell-box-spheres": (0.12, 16, 1e-3),  # LTC Beckmann + dielectric spheres (may_leak), areal lights
 }
 
 
@@ -245,8 +249,11 @@ def test_sponza_proxy_image_parity(rd, oracle, sponza_small):
     """LTC-GGX + diffuse, bilinear textures, bump mapping, point light, constant sky."""
     img, ref, kg, ko = render_both(rd, oracle, sponza_small)
     rel, within = image_metrics(img, ref, "test_sponza_proxy_image_parity")
-    assert rel <= 1e-2 and within >= 0.99, (rel, within)
-    assert abs(int(kg.path_rays) - int(ko.path_rays)) <= 1e-3 * ko.path_rays
+    # 99.99 % of the pixels are bit-identical (pinned libm); what differs is one or two paths that meet an epsilon-band tie the
+    # kd-tree and the BVH resolve differently -- at 8 spp and the default clamp of 1e7 a single such path is most of a pixel and
+    # 2e-3 of the whole image's L2 (the full-size test holds the SURVEY 8(d) gate: 2.2e-4 at 256 spp)
+    assert rel <= 5e-3 and within >= 0.999, (rel, within)
+    assert abs(int(kg.path_rays) - int(ko.path_rays)) <= 1e-4 * ko.path_rays
     assert np.isfinite(img).all()
 
 
@@ -255,7 +262,7 @@ def test_sponza4_sphere_light_clamp_russian(rd, oracle):
     wl = Workload("sponza4-2160p", scale=0.04, spp=8)   # sphere light size 1, depth 4, clamp 5, russian 0.6
     img, ref, kg, ko = render_both(rd, oracle, wl)
     rel, within = image_metrics(img, ref, "test_sponza4_sphere_light_clamp_russian")
-    assert rel <= 2e-2 and within >= 0.98, (rel, within)
+    assert rel <= 5e-3 and within >= 0.999, (rel, within)    # measured 2.6e-3 / 0.9998 (8 spp: see test_sponza_proxy_image_parity)
     assert img.max() <= wl.clamp * (1 + 1e-6)
 
 
@@ -267,8 +274,8 @@ def test_dragon_sponza_config4_small(rd, oracle):
     assert wl.reverse == 3 and wl.depth == 40
     img, ref, kg, ko = render_both(rd, oracle, wl)
     rel, within = image_metrics(img, ref, "test_dragon_sponza_config4_small")
-    assert rel <= 3e-2 and within >= 0.97, (rel, within)
-    assert abs(int(kg.path_rays) - int(ko.path_rays)) <= 2e-3 * ko.path_rays
+    assert rel <= 1e-3 and within >= 0.999, (rel, within)    # measured 1.3e-4 / 0.9998 (reverse = 3: splats are float atomics)
+    assert abs(int(kg.path_rays) - int(ko.path_rays)) <= 1e-4 * ko.path_rays
 
 
 def test_deep_tree_stack_overflow_variant(rd, oracle):
@@ -369,9 +376,8 @@ def test_material_zoo_image_parity(rd, oracle):
         ao, co, ko = o.render_round(cam, prm, oracle.generate_task_list(W, H))
         img, ref = ag / cg[..., None], ao / co[..., None]
         rel, within = image_metrics(img, ref, "test_material_zoo_image_parity")
-        # delta BxDFs + sin/cos ulp differences flip a few paths: outlier budget 1 %
-        assert rel <= 2e-2 and within >= 0.99, (lens, rel, within)
-        assert abs(int(kg.path_rays) - int(ko.path_rays)) <= 2e-3 * ko.path_rays
+        assert rel <= 1e-4 and within >= 0.999, (lens, rel, within)   # measured 1.2e-5 / 0.9999
+        assert abs(int(kg.path_rays) - int(ko.path_rays)) <= 1e-4 * ko.path_rays
 
 
 def test_bidirectional_reverse_parity(rd, oracle):
@@ -410,7 +416,7 @@ def test_bidirectional_reverse_parity(rd, oracle):
 
 
 # ----------------------------------------------------------------------- boundary behaviour, properties
-FULL_SIZE_SPONZA_REL, FULL_SIZE_SPONZA_WITHIN = 1e-2, 0.99
+FULL_SIZE_SPONZA_REL, FULL_SIZE_SPONZA_WITHIN = 1e-3, 0.999   # SURVEY 8(d)'s gate, on the benchmark workload at full size (measured 2.2e-4 / 0.9993)
 
 
 def test_round_properties_cornell_config2_size(rd, oracle):
@@ -740,3 +746,23 @@ def test_texture_lookup_unit_level(rd, oracle, product_lib):
     assert np.array_equal(rgb.view(np.uint32), ref.view(np.uint32))
     assert np.array_equal(sr.view(np.uint32), rr.view(np.uint32)) and np.array_equal(sbm.view(np.uint32), rb.view(np.uint32))
     assert product_lib.rgk_texture_sample(g.h, 1, np.array([77], np.int32).ctypes.data, uv.ctypes.data, rgb.ctypes.data, sr.ctypes.data, sbm.ctypes.data) == -1
+
+
+def test_pinned_libm_same_bits_on_gpu_and_cpu(oracle, product_lib):
+    """include/rgk_libm.h compiled by hipcc for gfx950 and by g++ for the host: the same bits for every input (1 M per
+    function, the ranges the path produces plus edge cases) -- what makes whole images bit-identical."""
+    L = oracle.lib()
+    rng = np.random.default_rng(31)
+    x = np.concatenate([rng.uniform(0, 2 * np.pi, 600000), rng.uniform(-50, 50, 200000), [0.0, -0.0, np.pi, np.pi / 2, 1e-30, 6.2831855]]).astype(np.float32)
+    u = np.concatenate([rng.uniform(-1, 1, 600000), 1 - rng.uniform(0, 1e-4, 100000), -1 + rng.uniform(0, 1e-4, 100000), [1, -1, 0, -0.0, 0.5, -0.5, 1.5, np.nan]]).astype(np.float32)
+    d = rng.normal(size=(800000, 2)).astype(np.float32)
+    d[:1000, 0] = 0.0; d[1000:2000, 1] = 0.0; d[2000:2100] *= -0.0
+    for fn, a, b in ((0, x, None), (1, x, None), (2, u, None), (3, u, None), (4, d[:, 0].copy(), d[:, 1].copy())):
+        a = np.ascontiguousarray(a); b = a if b is None else np.ascontiguousarray(b)
+        cpu = np.zeros(len(a), np.float32); gpu = np.zeros(len(a), np.float32)
+        assert L.orc_libm(fn, len(a), a.ctypes.data, b.ctypes.data, cpu.ctypes.data) == 0
+        assert product_lib.rgk_libm_eval(fn, len(a), a.ctypes.data, b.ctypes.data, gpu.ctypes.data) == 0
+        same = cpu.view(np.uint32) == gpu.view(np.uint32)
+        both_nan = np.isnan(cpu) & np.isnan(gpu)
+        record_parity(f"test_pinned_libm_same_bits_on_gpu_and_cpu:fn{fn}", n=len(a), bit_identical=float((same | both_nan).mean()))
+        assert (same | both_nan).all(), (fn, a[~(same | both_nan)][:5], cpu[~(same | both_nan)][:5], gpu[~(same | both_nan)][:5])
