@@ -809,7 +809,11 @@ static Spectrum bxdf_value(const Scene& sc, const Material& m, vec3 Vi, vec3 Vr,
     case RGK_BXDF_LTC_GGX: {
         if (Vi.z <= 0 || Vr.z <= 0) return Spectrum(0);
         LTCdef ltc{sc.ltc[m.kind == RGK_BXDF_LTC_GGX].data(), 64};
-        return sc.TexSpectrum(m.color, uv) * ltc_GetPDF(ltc, BxDFUpVector, Vi, Vr, m.roughness);
+        Spectrum spec = sc.TexSpectrum(m.color, uv);
+        // Q6 (defined): a black lobe is not evaluated.  The reference forms 0 * pdf, which is 0 -- and the same bits as
+        // here -- unless the pdf is NaN (view exactly along N: singular frame, ltc.cpp:62-69), where it poisons the path.
+        if (spec.r == 0.0f && spec.g == 0.0f && spec.b == 0.0f) return Spectrum(0);
+        return spec * ltc_GetPDF(ltc, BxDFUpVector, Vi, Vr, m.roughness);
     }
     case RGK_BXDF_LTC_BECKMANN_DIFFUSE:
     case RGK_BXDF_LTC_GGX_DIFFUSE: {
@@ -817,6 +821,7 @@ static Spectrum bxdf_value(const Scene& sc, const Material& m, vec3 Vi, vec3 Vr,
         LTCdef ltc{sc.ltc[m.kind == RGK_BXDF_LTC_GGX_DIFFUSE].data(), 64};
         Spectrum diff = sc.TexSpectrum(m.diffuse, uv);
         Spectrum spec = sc.TexSpectrum(m.color, uv);
+        if (spec.r == 0.0f && spec.g == 0.0f && spec.b == 0.0f) return diff / PI_F; // Q6, as above (18 of Sponza's 20 materials have Ks = 0)
         return spec * ltc_GetPDF(ltc, BxDFUpVector, Vi, Vr, m.roughness) + diff / PI_F;
     }
     }

@@ -71,6 +71,7 @@ __device__ __forceinline__ float len3(f3 v) { return sqrtf(dot3(v, v)); }
 __device__ __forceinline__ f3 norm3(f3 v) { return v * (1.0f / sqrtf(dot3(v, v))); }
 __device__ __forceinline__ float comp(f3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
 __device__ __forceinline__ float max3c(f3 v) { return fmaxf(fmaxf(v.x, v.y), v.z); }
+__device__ __forceinline__ bool is_zero3(f3 v) { return v.x == 0.f && v.y == 0.f && v.z == 0.f; }
 __device__ __forceinline__ float glm_angle(f3 a, f3 b) { return rgk_acosf(fminf(fmaxf(dot3(a, b), -1.0f), 1.0f)); }
 
 struct quatf {
@@ -432,7 +433,9 @@ __device__ __forceinline__ f3 bxdf_value_leaf(const DevScene& sc, const DevMater
     case RGK_BXDF_LTC_GGX: {
         if (Vi.z <= 0 || Vr.z <= 0) return zero;
         const uint32_t tab = (m.kind == RGK_BXDF_LTC_GGX) ? 0u : RGK_LTC_TABLE_BYTES; // GGX table, then Beckmann, in one buffer
-        return tex_get(sc, m.t_color, uv) * ltc_pdf(sc.ltc, tab, Vi, Vr, m.roughness);
+        const f3 spec = tex_get(sc, m.t_color, uv);
+        if (is_zero3(spec)) return zero; // Q6: a black lobe is not evaluated (the reference multiplies 0 by the pdf)
+        return spec * ltc_pdf(sc.ltc, tab, Vi, Vr, m.roughness);
     }
     case RGK_BXDF_LTC_BECKMANN_DIFFUSE:
     case RGK_BXDF_LTC_GGX_DIFFUSE: {
@@ -440,6 +443,7 @@ __device__ __forceinline__ f3 bxdf_value_leaf(const DevScene& sc, const DevMater
         const uint32_t tab = (m.kind == RGK_BXDF_LTC_GGX_DIFFUSE) ? 0u : RGK_LTC_TABLE_BYTES; // GGX table, then Beckmann, in one buffer
         f3 diff = tex_get(sc, m.t_diffuse, uv);
         f3 spec = tex_get(sc, m.t_color, uv);
+        if (is_zero3(spec)) return diff / RGK_PI_F; // Q6
         return spec * ltc_pdf(sc.ltc, tab, Vi, Vr, m.roughness) + diff / RGK_PI_F;
     }
     default: return zero;
@@ -548,12 +552,15 @@ __device__ RGK_SLOW_ATTR void bxdf_sample_slow(const DevScene& sc, int mat, f3 V
 // bxdf_value; mirrors, dielectrics, transparents and mixes take the generic route.
 struct MatPrep {
     bool fast;
+    bool lobe; // the LTC lobe can contribute: its colour is not exactly black (Q6: the reference multiplies a black colour by the pdf;
+               // here the lobe is then neither looked up nor evaluated, and a sample of it is the zero weight it would have been)
     f3 diffc, colorc;
     LtcM Mv, Ms;
 };
 __device__ __forceinline__ bool mat_is_fast(uint32_t k) { return k == RGK_BXDF_DIFFUSE || k >= RGK_BXDF_LTC_BECKMANN; } // MatPrep::fast
 __device__ __forceinline__ void mat_prepare(const DevScene& sc, const DevMaterial& m, float2 uv, f3 VrL, bool need_sample, MatPrep& e) {
     e.fast = false;
+    e.lobe = false;
     e.diffc = e.colorc = mk3(0.f, 0.f, 0.f);
     const uint32_t k = m.kind;
     if (k == RGK_BXDF_DIFFUSE) {
@@ -563,10 +570,13 @@ __device__ __forceinline__ void mat_prepare(const DevScene& sc, const DevMateria
         e.fast = true;
         e.colorc = tex_get(sc, m.t_color, uv);
         if (k >= RGK_BXDF_LTC_BECKMANN_DIFFUSE) e.diffc = tex_get(sc, m.t_diffuse, uv);
-        const uint32_t tab = (k == RGK_BXDF_LTC_GGX || k == RGK_BXDF_LTC_GGX_DIFFUSE) ? 0u : RGK_LTC_TABLE_BYTES; // GGX table, then Beckmann, in one buffer
-        const float theta = ltc_theta(VrL);
-        e.Mv = ltc_bilinear(sc.ltc, tab, theta, m.roughness);
-        e.Ms = (theta >= RGK_PI_F / 4.0f || !need_sample) ? e.Mv : ltc_bilinear(sc.ltc, tab, RGK_PI_F / 4.0f, m.roughness);
+        e.lobe = !is_zero3(e.colorc);
+        if (e.lobe) {
+            const uint32_t tab = (k == RGK_BXDF_LTC_GGX || k == RGK_BXDF_LTC_GGX_DIFFUSE) ? 0u : RGK_LTC_TABLE_BYTES; // GGX table, then Beckmann, in one buffer
+            const float theta = ltc_theta(VrL);
+            e.Mv = ltc_bilinear(sc.ltc, tab, theta, m.roughness);
+            e.Ms = (theta >= RGK_PI_F / 4.0f || !need_sample) ? e.Mv : ltc_bilinear(sc.ltc, tab, RGK_PI_F / 4.0f, m.roughness);
+        }
     }
 }
 // GENERIC = false: the caller guarantees a fast-route material (the generic route is compiled out)
@@ -588,6 +598,7 @@ __device__ __forceinline__ void mat_sample(const DevScene& sc, int mat, const De
         weight = e.diffc;
         return;
     }
+    if (!e.lobe) { dir = mk3(0.f, 0.f, 1.f); weight = zero; return; } // a black lobe: weight 0 ends the path, its direction is never read
     f3 v = ltc_random_M(e.Ms, VrL, hemisphere_cosine_z(u));
     dir = v;
     weight = (v.z <= 0) ? zero : e.colorc;
@@ -597,6 +608,7 @@ __device__ __forceinline__ f3 mat_value(const DevScene& sc, int mat, const DevMa
     if (GENERIC && !e.fast) return bxdf_value_slow(sc, mat, ViL, VrL, uv);
     if (ViL.z <= 0 || VrL.z <= 0) return mk3(0.f, 0.f, 0.f);
     if (m.kind == RGK_BXDF_DIFFUSE) return e.diffc / RGK_PI_F;
+    if (!e.lobe) return (m.kind >= RGK_BXDF_LTC_BECKMANN_DIFFUSE) ? e.diffc / RGK_PI_F : mk3(0.f, 0.f, 0.f);
     float pdf = ltc_pdf_M(e.Mv, ViL, VrL);
     if (m.kind >= RGK_BXDF_LTC_BECKMANN_DIFFUSE) return e.colorc * pdf + e.diffc / RGK_PI_F;
     return e.colorc * pdf;
@@ -611,6 +623,7 @@ __device__ __forceinline__ f3 mat_value_at(const DevScene& sc, int mat, const De
     if (GENERIC && !e.fast) return bxdf_value_slow(sc, mat, Vi, Vr, uv);
     if (Vi.z <= 0 || Vr.z <= 0) return mk3(0.f, 0.f, 0.f);
     if (m.kind == RGK_BXDF_DIFFUSE) return e.diffc / RGK_PI_F;
+    if (!e.lobe) return (m.kind >= RGK_BXDF_LTC_BECKMANN_DIFFUSE) ? e.diffc / RGK_PI_F : mk3(0.f, 0.f, 0.f);
     const uint32_t tab = (m.kind == RGK_BXDF_LTC_GGX || m.kind == RGK_BXDF_LTC_GGX_DIFFUSE) ? 0u : RGK_LTC_TABLE_BYTES;
     const float pdf = ltc_pdf(sc.ltc, tab, Vi, Vr, m.roughness);
     if (m.kind >= RGK_BXDF_LTC_BECKMANN_DIFFUSE) return e.colorc * pdf + e.diffc / RGK_PI_F;
@@ -623,6 +636,7 @@ __device__ __forceinline__ f3 bxdf_value_fastkind(const DevScene& sc, const DevM
     if (Vi.z <= 0 || Vr.z <= 0) return mk3(0.f, 0.f, 0.f);
     const f3 diff = mk3(diffc.x, diffc.y, diffc.z), spec = mk3(colorc.x, colorc.y, colorc.z);
     if (m.kind == RGK_BXDF_DIFFUSE) return diff / RGK_PI_F;
+    if (is_zero3(spec)) return (m.kind >= RGK_BXDF_LTC_BECKMANN_DIFFUSE) ? diff / RGK_PI_F : mk3(0.f, 0.f, 0.f); // Q6
     const uint32_t tab = (m.kind == RGK_BXDF_LTC_GGX || m.kind == RGK_BXDF_LTC_GGX_DIFFUSE) ? 0u : RGK_LTC_TABLE_BYTES;
     if (m.kind >= RGK_BXDF_LTC_BECKMANN_DIFFUSE) return spec * ltc_pdf(sc.ltc, tab, Vi, Vr, m.roughness) + diff / RGK_PI_F;
     return spec * ltc_pdf(sc.ltc, tab, Vi, Vr, m.roughness);

@@ -673,6 +673,10 @@ def test_bxdf_value_and_sample_unit_level(rd, oracle, product_lib):
         m = sb.new_material(f"ltc{k}", capi.BXDF_LTC_GGX_DIFFUSE if k % 2 else capi.BXDF_LTC_BECKMANN_DIFFUSE)
         m["tex_diffuse"] = sb.create_solid_texture((0.6, 0.5, 0.4)); m["tex_color"] = sb.create_solid_texture((0.3, 0.3, 0.25)); m["roughness"] = r
         sb.register_material(m)
+    for k, kind in enumerate((capi.BXDF_LTC_GGX_DIFFUSE, capi.BXDF_LTC_BECKMANN)):   # black lobes (Ks = 0, as 18 of Sponza's 20 materials): Q6
+        m = sb.new_material(f"black{k}", kind)
+        m["tex_diffuse"] = sb.create_solid_texture((0.6, 0.5, 0.4)); m["tex_color"] = sb.create_solid_texture((0.0, 0.0, 0.0)); m["roughness"] = 0.3
+        sb.register_material(m)
     desc = sb.to_desc()
     g, o = rd.Scene(desc), oracle.OracleScene(desc)
     L = oracle.lib()
@@ -699,9 +703,9 @@ def test_bxdf_value_and_sample_unit_level(rd, oracle, product_lib):
         assert np.array_equal(np.isnan(val), np.isnan(ref_v))
         rel_v = float((ev / sv).max())
         exact_v = float((val.view(np.uint32) == ref_v.view(np.uint32)).all(axis=1).mean())
-        ok = ~np.isnan(ref_d).any(axis=1)
+        ok = ~np.isnan(ref_d).any(axis=1) & (ref_w.max(axis=1) > 0)   # a zero weight ends the path: its direction is never read (path_tracer.cpp:268-279)
         err_d = float(np.abs(d[ok] - ref_d[ok]).max())
-        exact_d = float((d.view(np.uint32) == ref_d.view(np.uint32)).all(axis=1).mean())
+        exact_d = float((d[ok].view(np.uint32) == ref_d[ok].view(np.uint32)).all(axis=1).mean())
         record_parity(f"test_bxdf_value_and_sample_unit_level:route{route}", n=n, value_max_rel=rel_v, value_bit_identical=exact_v,
                       sample_dir_max_abs=err_d, sample_dir_bit_identical=exact_d, nonzero_values=float((ref_v.max(axis=1) > 0).mean()))
         assert rel_v <= 2e-4 and err_d <= 2e-5        # libm only: acosf (the LTC table angle: a 1-ulp theta moves the bilinear weights), sinf / cosf (disc sample)
