@@ -159,10 +159,12 @@ def main():
     # (round 1 reported it as one: 1.78); it is kept as the algorithmic rate only.
     bytes_per_ray = 32 + 4 + 16 + nodes_per_ray * info.node_bytes + tris_per_ray * info.tri_bytes
     stream = {  # bytes every launch of the class must move through HBM once (records in, records out), summed over the timed steps
-        "k_trace_closest": 48.0 * R_l,                                   # ray 32 in, hit 16 out
+        "k_trace_closest": 48.0 * R_l - 32.0 * P_l,                      # ray 32 in (bounce 0 makes its camera rays itself), hit 16 out
         "k_trace_shadow": 48.0 * S_l,                                    # shadow ray 48 in (+ the slot sums of visible ones)
-        "k_shade": 68.0 * R_l + 64.0 * (R_l - P_l) + 48.0 * S_l,         # ray 32 + hit 16 + light 16 + seed 4; thr 16 w + 16 r and next ray 32 per continuing path; shadow ray 48 out
-        "raygen_resolve": (64.0 + 8.0 + 16.0) * P_l,                     # raygen: ray 32 + light 16 + slot sum 16 out, pixel + seed 8 in; resolve: slot sum 16 in
+        # hit 16 + seed 4 per vertex; ray 32 + light 16 + path state 16 in per vertex past the first; path state 16 + light 16 (first
+        # vertex) + next ray 32 out per continuing path; slot sum 16 out per path; shadow ray 48 out
+        "k_shade": 20.0 * R_l + 64.0 * (R_l - P_l) + (48.0 + 16.0) * (R_l - P_l) + 16.0 * P_l + 48.0 * S_l,
+        "raygen_resolve": 16.0 * P_l,                                    # resolve: slot sum 16 in (there is no ray-generation kernel)
     }
     prof, prof_name = None, None
     try:

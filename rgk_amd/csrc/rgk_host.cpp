@@ -1073,13 +1073,15 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
             uint32_t* cl = s->counters.p + RGK_CNT_TOTAL;   // light-phase counters
             if (R == 0) {
                 TIMED(3, rgk_launch_init_counters(st, cn, n0));
-                TIMED(3, rgk_launch_raygen(st, s->dev, cam, pp, s->rayA[0].p, s->rayB[0].p, s->thr.p, s->tot.p));
                 uint32_t ub = n0; // upper bound on bounce b's queue
                 for (uint32_t b = 0; b < prm->depth && ub > 0; b++) {
                     int q = b & 1;
                     rgk_launch_set_bound(ub, ub);
-                    TIMED(0, rgk_launch_trace_closest(st, s->dev, s->tcfg, count_stats, s->rayA[q].p, s->rayB[q].p, nullptr, s->hit.p,
-                                                      cn + RGK_CNT_QUEUE + b, cn + RGK_CNT_FETCH_T + b, s->stats.p));
+                    if (b == 0) // no ray queue at bounce 0: the camera ray of slot i is made where it is traced and shaded
+                        TIMED(0, rgk_launch_trace_camera(st, s->dev, cam, pp, s->tcfg, count_stats, s->hit.p, cn + RGK_CNT_QUEUE, cn + RGK_CNT_FETCH_T, s->stats.p));
+                    else
+                        TIMED(0, rgk_launch_trace_closest(st, s->dev, s->tcfg, count_stats, s->rayA[q].p, s->rayB[q].p, nullptr, s->hit.p,
+                                                          cn + RGK_CNT_QUEUE + b, cn + RGK_CNT_FETCH_T + b, s->stats.p));
                     TIMED(2, rgk_launch_shade(st, s->dev, cam, pp, b, s->rayA[q].p, s->rayB[q].p, s->hit.p, s->thr.p, s->tot.p,
                                               s->rayA[q ^ 1].p, s->rayB[q ^ 1].p, s->shA.p, s->shB.p, s->shC.p, cn));
                     TIMED(1, rgk_launch_trace_shadow(st, s->dev, s->tcfg, count_stats, s->shA.p, s->shB.p, s->shC.p, s->tot.p, nullptr,

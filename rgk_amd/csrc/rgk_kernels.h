@@ -38,7 +38,7 @@ struct PassParams {
     const uint32_t* pix_xy;   // x | y << 16, per pixel of the round
     const uint32_t* pix_seed; // PathTracer::samplerSeed for that pixel (a2)
     const float* htab;        // halton_raw(hdim, s) for hdim < 192, s < multisample: htab[hdim * multisample + s]
-    float4* light;            // per slot: the path's light {pos.xyz, code}, written by k_raygen
+    float4* light;            // per slot: the path's light {pos.xyz, code}, written by the first vertex of a path that goes on
     // bidirectional state (reverse > 0), null otherwise; per slot with stride `batch`
     float4* lstart;           // light_at_path_start.rgb
     float4* lv;               // light vertices: lv[(k*RGK_LV_FLOAT4 + c) * batch + slot], c: see RGK_LV_FLOAT4
@@ -52,8 +52,6 @@ struct PassParams {
 void rgk_launch_init_counters(hipStream_t st, uint32_t* counters, uint32_t n0);
 void rgk_launch_build_pixel_list(hipStream_t st, const rgk_tile* tiles, const uint32_t* tile_off, uint32_t n_tiles, uint32_t* pix_xy, uint32_t* pix_seed);
 void rgk_launch_build_halton_table(hipStream_t st, const DevScene& sc, uint32_t S, float* htab);
-void rgk_launch_raygen(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, float4* rayA, float4* rayB,
-                       float4* thr, float4* tot);
 // traversal-stack configuration of a scene: entries its tree can need, how many of them live in LDS, overflow area
 struct RgkTraceCfg {
     int stack, lds;
@@ -62,6 +60,8 @@ struct RgkTraceCfg {
 int rgk_trace_grid(int lds_entries);
 // upper bounds on the queue lengths the following launches consume (grids shrink accordingly); 0xffffffff = unknown
 void rgk_launch_set_bound(uint32_t items, uint32_t shadow_items); // workgroups of a persistent trace launch (LDS-limited residency x 256 CUs)
+void rgk_launch_trace_camera(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, const RgkTraceCfg& tc, bool count_stats, float4* hit,
+                             const uint32_t* count_ptr, uint32_t* fetch, unsigned long long* stats);
 void rgk_launch_trace_closest(hipStream_t st, const DevScene& sc, const RgkTraceCfg& tc, bool count_stats, const float4* rayA, const float4* rayB,
                               const float2* nearfar, float4* hit, const uint32_t* count_ptr, uint32_t* fetch, unsigned long long* stats);
 void rgk_launch_trace_shadow(hipStream_t st, const DevScene& sc, const RgkTraceCfg& tc, bool count_stats, const float4* shA, const float4* shB,

@@ -18,52 +18,18 @@
 
 #include "rgk_trace.h" // K2 / K5: persistent traversal with lane refill
 
-// ------------------------------------------------------------------ K1: ray generation
-// Camera::GetPixelRay / GetPixelRayLens, reference src/camera.cpp:26-46; Ray ctor src/ray.hpp:10-13
-__device__ __forceinline__ void camera_ray(const DevCamera& cam, int x, int y, int xres, int yres, float2 off, float2 lens, f3& o, f3& d) {
-    float fx = (x + off.x) / (float)(xres), fy = (y + off.y) / (float)(yres);
-    f3 vs = mk3(cam.viewscreen[0], cam.viewscreen[1], cam.viewscreen[2]);
-    f3 vx = mk3(cam.viewscreen_x[0], cam.viewscreen_x[1], cam.viewscreen_x[2]);
-    f3 vy = mk3(cam.viewscreen_y[0], cam.viewscreen_y[1], cam.viewscreen_y[2]);
-    f3 p = vs + fx * vx + fy * vy;
-    o = mk3(cam.origin[0], cam.origin[1], cam.origin[2]);
-    if (cam.lens_size != 0.0f) {
-        float2 dsc = disc_uniform(lens);
-        float lx = dsc.x * cam.lens_size, ly = dsc.y * cam.lens_size;
-        o = o + lx * mk3(cam.left[0], cam.left[1], cam.left[2]) + ly * mk3(cam.up[0], cam.up[1], cam.up[2]);
-    }
-    d = norm3(p - o);
-}
-
-__global__ __launch_bounds__(256) void k_raygen(const DevScene sc, const DevCamera cam, const PassParams pp, float4* __restrict__ rayA,
-                                                 float4* __restrict__ rayB, float4* __restrict__ thr, float4* __restrict__ tot) {
-    const uint32_t n = pp.npix * pp.ns;
-    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n; slot += gridDim.x * blockDim.x) {
-        uint32_t srel = slot / pp.npix, j = slot - srel * pp.npix;
-        uint32_t pix = pp.pix_xy[pp.j0 + j], seed = pp.pix_seed[pp.j0 + j];
-        uint32_t s = pp.s0 + srel;
-        const SamplerTab tb = {pp.htab, pp.multisample};
-        float2 jit = sample2d_t(tb, seed, s, 0);
-        float2 lens = make_float2(0.f, 0.f);
-        uint32_t base2d = 1u;
-        if (cam.lens_size != 0.0f) { lens = sample2d_t(tb, seed, s, 1); base2d = 2u; }
-        f3 o, d;
-        camera_ray(cam, (int)(pix & 0xffff), (int)(pix >> 16), (int)pp.xres, (int)pp.yres, jit, lens, o, d);
-        // TracePath: areal_sample, (lightdir_sample), GetRandomLight(Get2D, Get1D, areal_sample) -- path_tracer.cpp:315-322
-        f3 lpos;
-        uint32_t lcode = light_code(sc, sample2d_t(tb, seed, s, base2d + 2u), sample1d_t(tb, seed, s, 0u),
-                                    sample2d_t(tb, seed, s, base2d), lpos);
-        pp.light[slot] = make_float4(lpos.x, lpos.y, lpos.z, __uint_as_float(lcode));
-        rayA[slot] = make_float4(o.x, o.y, o.z, d.x);
-        rayB[slot] = make_float4(d.y, d.z, __uint_as_float(0xffffffffu), __uint_as_float(slot));
-        // thr[slot] is implicit until the first vertex writes it: {1, 1, 1 | n = 0, 1-D counter = 1} (k_shade, bounce 0)
-        tot[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-}
+// ------------------------------------------------------------------ K1: ray generation (camera_ray, camera_ray_of_slot: rgk_trace.h)
+// (Unidirectional rounds have no ray-generation kernel: bounce 0 derives the camera ray from the slot number in the traversal
+// kernel and again in the shading kernel, and the first vertex samples the path's light and starts its sum -- see
+// k_trace_camera and k_shade<GENERIC, FIRST = true>.  The bidirectional kernels keep theirs, rgk_bdpt.h.)
 
 // ------------------------------------------------------------------ K3+K4+K6+K7: shade
 
-template <bool GENERIC>
+// FIRST = true: bounce 0.  Queue index == path slot, the ray is the slot's camera ray (not stored anywhere), the path state is
+// implicit {1, 1, 1 | n = 0, 1-D counter = 1}, the path's ONE light is sampled here (TracePath: areal_sample, (lightdir_sample),
+// GetRandomLight(Get2D, Get1D, areal_sample) -- path_tracer.cpp:315-322) and kept per slot for the later bounces of paths that
+// go on, and the slot's radiance sum STARTS here (written, not read-modified: nothing zeroes it beforehand).
+template <bool GENERIC, bool FIRST>
 __global__ __launch_bounds__(RGK_SHADE_BLOCK, RGK_SHADE_WAVES) void k_shade(const DevScene sc, const DevCamera cam, const PassParams pp, const uint32_t bounce,
                                                             const float4* __restrict__ rayA, const float4* __restrict__ rayB,
                                                             const float4* __restrict__ hit, float4* __restrict__ thr, float4* __restrict__ tot,
@@ -87,10 +53,18 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, RGK_SHADE_WAVES) void k_shade(cons
         bool cont = false, shadow = false, defer = false;
         float4 nA = make_float4(0, 0, 0, 0), nB = nA, sA = nA, sB = nA, sC = nA;
         if (valid) {
-            const float4 a = rayA[i], b = rayB[i], h = hit[i];
-            const uint32_t slot = __float_as_uint(b.w);
-            const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
-            const float4 st = bounce == 0 ? make_float4(1.f, 1.f, 1.f, __uint_as_float(1u << 16)) : thr[slot]; // k_raygen leaves it implicit
+            const float4 h = hit[i];
+            uint32_t slot;
+            f3 o, d;
+            if (FIRST) { slot = i; camera_ray_of_slot(cam, pp, slot, o, d); }
+            else {
+                const float4 a = rayA[i], b = rayB[i];
+                slot = __float_as_uint(b.w);
+                o = mk3(a.x, a.y, a.z); d = mk3(a.w, b.x, b.y);
+            }
+            const float4 st = FIRST ? make_float4(1.f, 1.f, 1.f, __uint_as_float(1u << 16)) : thr[slot];
+            f3 tot0 = mk3(0.f, 0.f, 0.f); // FIRST, fast launch: what this vertex adds to the (so far empty) sum of its slot
+            float4 li_keep = make_float4(0.f, 0.f, 0.f, 0.f);
             f3 cum = mk3(st.x, st.y, st.z);
             uint32_t bits = __float_as_uint(st.w);
             uint32_t n = (bits & 0xffffu) + 1u; // n++ at loop top, reference path_tracer.cpp:123
@@ -104,10 +78,13 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, RGK_SHADE_WAVES) void k_shade(cons
             if (tri < 0) {
                 // sky vertex: path_total += contribution * sky, reference path_tracer.cpp:137-146,409-415
                 f3 sky = skybox(sc, Vr);
-                float4 t = tot[slot];
                 f3 add = cum * sky;
-                t.x = t.x + add.x; t.y = t.y + add.y; t.z = t.z + add.z;
-                tot[slot] = t;
+                if (FIRST && !GENERIC) tot0 = mk3(0.f + add.x, 0.f + add.y, 0.f + add.z);
+                else {
+                    float4 t = tot[slot];
+                    t.x = t.x + add.x; t.y = t.y + add.y; t.z = t.z + add.z;
+                    tot[slot] = t;
+                }
             } else {
                 // one 128-byte line per triangle: {nA,uvA.x}{nB,uvA.y}{nC,uvB.x}{tA,uvB.y}{tB,uvC.x}{tC,uvC.y}{mat}
                 const uint32_t tsr = (uint32_t)tri * (uint32_t)sizeof(TriShade);
@@ -178,7 +155,13 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, RGK_SHADE_WAVES) void k_shade(cons
 
                     // ---- phase 3 for this vertex: NEE to the path's light, :427-460,485-496
                     {
-                        const float4 li = pp.light[slot];
+                        float4 li;
+                        if (FIRST) {
+                            f3 lpos;
+                            const uint32_t lcode = light_code(sc, sample2d_t(tb, seed, s, base2d + 2u), sample1d_t(tb, seed, s, 0u), sample2d_t(tb, seed, s, base2d), lpos);
+                            li = make_float4(lpos.x, lpos.y, lpos.z, __uint_as_float(lcode));
+                        } else li = pp.light[slot];
+                        li_keep = li;
                         const DLight L = light_from_code(sc, mk3(li.x, li.y, li.z), __float_as_uint(li.w));
                         f3 e_front = mk3(0.f, 0.f, 0.f);
                         if (dot3(faceN, Vr) > 0) e_front = mk3(mat.emission[0], mat.emission[1], mat.emission[2]);
@@ -186,9 +169,12 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, RGK_SHADE_WAVES) void k_shade(cons
                         f3 B = mk3(0.f, 0.f, 0.f);
                         if (has_e) {
                             B = clamp3(mk3(0.f, 0.f, 0.f) + e_front, pp.clamp) * contribution;
-                            float4 t = tot[slot];
-                            t.x = t.x + B.x; t.y = t.y + B.y; t.z = t.z + B.z;
-                            tot[slot] = t;
+                            if (FIRST && !GENERIC) tot0 = mk3(0.f + B.x, 0.f + B.y, 0.f + B.z);
+                            else {
+                                float4 t = tot[slot];
+                                t.x = t.x + B.x; t.y = t.y + B.y; t.z = t.z + B.z;
+                                tot[slot] = t;
+                            }
                         }
                         if (L.type >= 0) {
                             const f3 diff = pos - L.pos; // Ray(light.pos, p.pos, 20 eps), src/ray.hpp:15-22
@@ -227,10 +213,12 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, RGK_SHADE_WAVES) void k_shade(cons
                         nA = make_float4(no.x, no.y, no.z, nd.x);
                         nB = make_float4(nd.y, nd.z, __int_as_float(tri), __uint_as_float(slot));
                         thr[slot] = make_float4(cum.x, cum.y, cum.z, __uint_as_float((n & 0xffffu) | (c1 << 16)));
+                        if (FIRST) pp.light[slot] = li_keep;
                     }
                 }
                 } // !defer
             }
+            if (FIRST && !GENERIC) tot[slot] = make_float4(tot0.x, tot0.y, tot0.z, 0.f); // every slot of the pass passes here exactly once
         }
         // ---- K7: compaction into the next queues.
         {
@@ -495,11 +483,10 @@ void rgk_launch_build_halton_table(hipStream_t st, const DevScene& sc, uint32_t 
     k_build_halton_table<<<(n + 255) / 256, 256, 0, st>>>(sc, S, htab);
 }
 
-void rgk_launch_raygen(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, float4* rayA, float4* rayB, float4* thr, float4* tot) {
-    uint32_t n = pp.npix * pp.ns;
-    int grid = (int)((n + 255) / 256);
-    if (grid > 256 * 16) grid = 256 * 16;
-    k_raygen<<<grid, 256, 0, st>>>(sc, cam, pp, rayA, rayB, thr, tot);
+// bounce 0 of a unidirectional pass: camera rays generated in the traversal kernel (no queue)
+void rgk_launch_trace_camera(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, const RgkTraceCfg& tc, bool count_stats, float4* hit,
+                             const uint32_t* count_ptr, uint32_t* fetch, unsigned long long* stats) {
+    RGK_TRACE_DISPATCH(k_trace_camera, g_bound, sc, cam, pp, hit, count_ptr, fetch, stats, tc.ovf)
 }
 
 void rgk_launch_trace_closest(hipStream_t st, const DevScene& sc, const RgkTraceCfg& tc, bool count_stats, const float4* rayA, const float4* rayB,
@@ -516,9 +503,15 @@ void rgk_launch_trace_shadow(hipStream_t st, const DevScene& sc, const RgkTraceC
 void rgk_launch_shade(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t bounce, const float4* rayA,
                       const float4* rayB, const float4* hit, float4* thr, float4* tot, float4* nextA, float4* nextB, float4* shA,
                       float4* shB, float4* shC, uint32_t* counters) {
-    k_shade<false><<<bounded_grid(256 * 4 * 512 / RGK_SHADE_BLOCK, g_bound, RGK_SHADE_BLOCK), RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
-    // the vertices the first launch listed (materials on the generic BxDF route); returns at once when there are none
-    k_shade<true><<<bounded_grid(256 * 2 * 512 / RGK_SHADE_BLOCK, g_bound, RGK_SHADE_BLOCK), RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
+    const int g1 = bounded_grid(256 * 4 * 512 / RGK_SHADE_BLOCK, g_bound, RGK_SHADE_BLOCK), g2 = bounded_grid(256 * 2 * 512 / RGK_SHADE_BLOCK, g_bound, RGK_SHADE_BLOCK);
+    // the second launch shades the vertices the first one listed (materials on the generic BxDF route); it returns at once when there are none
+    if (bounce == 0) {
+        k_shade<false, true><<<g1, RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
+        k_shade<true, true><<<g2, RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
+    } else {
+        k_shade<false, false><<<g1, RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
+        k_shade<true, false><<<g2, RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
+    }
 }
 
 void rgk_launch_resolve(hipStream_t st, const PassParams& pp, const float4* tot, float4* pixsum, float* accum_rgb, uint32_t* accum_count) {

@@ -36,6 +36,37 @@
 #define RGK_REFILL_BELOW 24 // refill a wave when at most this many lanes still hold a ray (swept 8..60 with the majority walk: 24 best)
 #endif
 
+// ------------------------------------------------------------------ camera rays (K1)
+// Camera::GetPixelRay / GetPixelRayLens, reference src/camera.cpp:26-46; Ray ctor src/ray.hpp:10-13
+__device__ __forceinline__ void camera_ray(const DevCamera& cam, int x, int y, int xres, int yres, float2 off, float2 lens, f3& o, f3& d) {
+    float fx = (x + off.x) / (float)(xres), fy = (y + off.y) / (float)(yres);
+    f3 vs = mk3(cam.viewscreen[0], cam.viewscreen[1], cam.viewscreen[2]);
+    f3 vx = mk3(cam.viewscreen_x[0], cam.viewscreen_x[1], cam.viewscreen_x[2]);
+    f3 vy = mk3(cam.viewscreen_y[0], cam.viewscreen_y[1], cam.viewscreen_y[2]);
+    f3 p = vs + fx * vx + fy * vy;
+    o = mk3(cam.origin[0], cam.origin[1], cam.origin[2]);
+    if (cam.lens_size != 0.0f) {
+        float2 dsc = disc_uniform(lens);
+        float lx = dsc.x * cam.lens_size, ly = dsc.y * cam.lens_size;
+        o = o + lx * mk3(cam.left[0], cam.left[1], cam.left[2]) + ly * mk3(cam.up[0], cam.up[1], cam.up[2]);
+    }
+    d = norm3(p - o);
+}
+// The camera ray of path slot `slot` of the current pass (RenderPixel, reference src/path_tracer.cpp:53-61): pixel and sample from
+// the slot, pixel jitter = 2-D dimension 0, lens = 2-D dimension 1.  A few dozen instructions and two cached table reads, so
+// the bounce-0 traversal and the bounce-0 shading each derive it from the slot number instead of one kernel writing 32 bytes
+// per path for the other two to read back (k_raygen was 4 % of a Sponza round, all of it HBM traffic).
+__device__ __forceinline__ void camera_ray_of_slot(const DevCamera& cam, const PassParams& pp, uint32_t slot, f3& o, f3& d) {
+    const uint32_t srel = slot / pp.npix, j = slot - srel * pp.npix;
+    const uint32_t pix = pp.pix_xy[pp.j0 + j], seed = pp.pix_seed[pp.j0 + j];
+    const uint32_t s = pp.s0 + srel;
+    const SamplerTab tb = {pp.htab, pp.multisample};
+    const float2 jit = sample2d_t(tb, seed, s, 0);
+    float2 lens = make_float2(0.f, 0.f);
+    if (cam.lens_size != 0.0f) lens = sample2d_t(tb, seed, s, 1);
+    camera_ray(cam, (int)(pix & 0xffff), (int)(pix >> 16), (int)pp.xres, (int)pp.yres, jit, lens, o, d);
+}
+
 // Triangle::TestIntersection, reference src/primitives.cpp:75-166.  r0..r2 = TriIsect.
 __device__ __forceinline__ bool tri_test(const float4 r0, const float4 r1, const float4 r2, const f3 o, const f3 d,
                                          const float eps, float& t, float& alpha, float& beta) {
@@ -95,13 +126,14 @@ __device__ __forceinline__ float cvt_ubyte(uint32_t w, int c) { return (float)((
 //   q0 = {o.xyz, d.x}; q1 = {d.y, d.z, ignore | far, slot}; q2 = {radiance.rgb, near} (shadow only)
 // STACK: entries the tree can need (host bound); LDSN <= STACK of them live in LDS, the rest -- reached only on the
 // deepest walks of a deep tree -- in a per-lane global overflow area, so that a deep tree does not halve the occupancy.
-template <bool ANY, bool COUNT, int STACK, int LDSN>
+// RAYGEN (closest hit, bounce 0): there is no ray queue -- ray i is the camera ray of path slot i, made here.
+template <bool ANY, bool COUNT, int STACK, int LDSN, bool RAYGEN = false>
 __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float4* __restrict__ q0, const float4* __restrict__ q1,
                                                  const float4* __restrict__ q2, const float2* __restrict__ nearfar,
                                                  float4* __restrict__ hit, float4* __restrict__ tot, uint8_t* __restrict__ vis_out,
                                                  const int mode, float* __restrict__ splat_rgb,
                                                  const uint32_t count, uint32_t* __restrict__ fetch, int* __restrict__ stack, int* __restrict__ ovf, const uint32_t ostride,
-                                                 uint32_t& n_nodes, uint32_t& n_tris) {
+                                                 uint32_t& n_nodes, uint32_t& n_tris, const DevCamera* cam = nullptr, const PassParams* pp = nullptr) {
     const int lane = threadIdx.x & 63;
     const int stride = RGK_TRACE_BLOCK;
     const float eps = sc.epsilon;
@@ -136,17 +168,22 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
                 const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
                 if (!active && rank < avail) {
                     idx = w_next + rank;
-                    const float4 a = q0[idx], b = q1[idx];
-                    o = mk3(a.x, a.y, a.z); d = mk3(a.w, b.x, b.y);
                     float tn = 0.0f, tf = 10000.0f; // Ray::near / Ray::far defaults, src/ray.hpp:25-26
-                    if (ANY) {
-                        const float4 c = q2[idx];
-                        rad = mk3(c.x, c.y, c.z); tn = c.w; tf = b.z;
-                        slot = __float_as_uint(b.w);
+                    if (RAYGEN) {
+                        camera_ray_of_slot(*cam, *pp, idx, o, d);
                         ignore = 0xffffffffu;
                     } else {
-                        ignore = __float_as_uint(b.z);
-                        if (nearfar) { float2 nf = nearfar[idx]; tn = nf.x; tf = nf.y; }
+                        const float4 a = q0[idx], b = q1[idx];
+                        o = mk3(a.x, a.y, a.z); d = mk3(a.w, b.x, b.y);
+                        if (ANY) {
+                            const float4 c = q2[idx];
+                            rad = mk3(c.x, c.y, c.z); tn = c.w; tf = b.z;
+                            slot = __float_as_uint(b.w);
+                            ignore = 0xffffffffu;
+                        } else {
+                            ignore = __float_as_uint(b.z);
+                            if (nearfar) { float2 nf = nearfar[idx]; tn = nf.x; tf = nf.y; }
+                        }
                     }
                     best_t = __builtin_inff(); best_tri = -1; best_a = 0.f; best_b = 0.f;
                     float t0, t1;
@@ -309,6 +346,21 @@ __global__ __launch_bounds__(RGK_TRACE_BLOCK, (LDSN <= 16 ? RGK_TRACE_WAVES : 5)
     uint32_t n_nodes = 0, n_tris = 0;
     trace_persistent<false, COUNT, STACK, LDSN>(sc, rayA, rayB, nullptr, nearfar, hit, nullptr, nullptr, 0, nullptr, *count_ptr, fetch,
                                           lds_stack + threadIdx.x, ovf + (blockIdx.x * RGK_TRACE_BLOCK + threadIdx.x), gridDim.x * RGK_TRACE_BLOCK, n_nodes, n_tris);
+    if (COUNT) {
+        atomicAdd(&stats[0], (unsigned long long)n_nodes);
+        atomicAdd(&stats[1], (unsigned long long)n_tris);
+    }
+}
+
+// K1 + K2 at bounce 0: the camera rays of a pass, generated where they are traced (no ray queue; hit[slot] out)
+template <bool COUNT, int STACK, int LDSN>
+__global__ __launch_bounds__(RGK_TRACE_BLOCK, (LDSN <= 16 ? RGK_TRACE_WAVES : 5)) void k_trace_camera(const DevScene sc, const DevCamera cam, const PassParams pp,
+                                                                    float4* __restrict__ hit, const uint32_t* __restrict__ count_ptr,
+                                                                    uint32_t* __restrict__ fetch, unsigned long long* __restrict__ stats, int* __restrict__ ovf) {
+    __shared__ int lds_stack[LDSN * RGK_TRACE_BLOCK];
+    uint32_t n_nodes = 0, n_tris = 0;
+    trace_persistent<false, COUNT, STACK, LDSN, true>(sc, nullptr, nullptr, nullptr, nullptr, hit, nullptr, nullptr, 0, nullptr, *count_ptr, fetch,
+                                          lds_stack + threadIdx.x, ovf + (blockIdx.x * RGK_TRACE_BLOCK + threadIdx.x), gridDim.x * RGK_TRACE_BLOCK, n_nodes, n_tris, &cam, &pp);
     if (COUNT) {
         atomicAdd(&stats[0], (unsigned long long)n_nodes);
         atomicAdd(&stats[1], (unsigned long long)n_tris);
