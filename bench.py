@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="resolution scale (testing only; invalidates the number)")
     ap.add_argument("--spp", type=int, default=None, help="override samples per pixel (testing only)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="strong")
+    ap.add_argument("--emulate-shard", type=int, default=0, help="diagnostic: ONE rank's share of a K-GPU strong-scaled round (tiles i %% K == 0) on this GPU, no reduce; not a benchmark number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + RGK_FORCE_DEVICE=0 rehearses N ranks on one GPU")
@@ -109,6 +110,18 @@ def main():
 
     drv = rd.RenderDriver(scene, Cfg, wl.camera, rank=rank, world_size=world, device=device, flags=capi.FLAG_TIME_KERNELS,
                           host_reduce=(args.backend != "nccl"))
+
+    if args.emulate_shard > 1:  # what one rank of a K-GPU run computes per round (its fixed per-round costs included)
+        drv.rank, drv.world_size = 0, args.emulate_shard
+        import types
+
+        def _round(self, reduce=True):
+            tiles = rd.generate_task_list(self.cfg.xres, self.cfg.yres, rd.SEEDSTART, self.seedcount)
+            self.seedcount += len(tiles)
+            mine = rd.shard_tiles(tiles, 0, args.emulate_shard)
+            torch.cuda.current_stream(self.device).synchronize()
+            return self.scene.render_round_device(self.camera, self.params, mine, self.total_ob.data.data_ptr(), self.total_ob.count.data_ptr())
+        drv.render_round = types.MethodType(_round, drv)
 
     def barrier():
         if world > 1:
@@ -175,12 +188,19 @@ def main():
         prof = None
 
     def prof_rec(kernel):
+        """Launch-weighted sum of the profiled instantiations of a kernel class (the non-counting ones): k_trace_closest =
+        k_trace_camera (bounce 0) + k_trace_closest (later bounces), k_shade = its first-bounce and later-bounce variants."""
         if not prof:
             return None
-        for k, r in prof.items():  # the non-counting instantiation of the template
-            if k.startswith(kernel) and "<true" not in k and (kernel != "k_shade" or k.startswith("k_shade<false>")):
-                return r
-        return None
+        names = {"k_trace_closest": ("k_trace_camera<false", "k_trace_closest<false"), "k_trace_shadow": ("k_trace_shadow<false",),
+                 "k_shade": ("k_shade<false, true>", "k_shade<false, false>"), "raygen_resolve": ("k_resolve",)}[kernel]
+        recs = [r for k, r in prof.items() if k.startswith(names)]
+        if not recs:
+            return None
+        n = sum(r["launches_profiled"] for r in recs)
+        w = lambda key: sum((r.get(key) or 0.0) * r["launches_profiled"] for r in recs) / n
+        return {"avg_ms": w("avg_ms"), "valu_slow_pipe_cycles": w("valu_slow_pipe_cycles"), "valu_issue_cycles": w("valu_issue_cycles"),
+                "valu_slow_pipe_frac": w("valu_slow_pipe_frac"), "lane_util": w("lane_util"), "hbm_bytes_per_launch": w("hbm_bytes_per_launch") or None}
 
     kernels = []
     for k in ("k_trace_closest", "k_shade", "k_trace_shadow", "raygen_resolve"):
@@ -193,10 +213,12 @@ def main():
         if pr and rec["avg_launch_ms"]:
             live_s = rec["avg_launch_ms"] * 1e-3
             rec.update({
-                "source": f"profiles/{prof_name}", "profile_avg_launch_ms": pr["avg_ms"],
-                # VALU issue: instruction-class counts x measured issue cycles, against 1024 SIMDs x 2.4 GHz x the LIVE launch time
-                "valu_issue_frac": round(pr["valu_issue_cycles"] / (1024 * 2.4e9 * live_s), 4),
-                "valu_issue_frac_at_measured_clock": pr["valu_issue_frac"], "lane_util": pr["lane_util"],
+                "source": f"profiles/{prof_name}", "profile_avg_launch_ms": round(pr["avg_ms"], 4),
+                # VALU: the non-fp32 ("slow") pipe's busy cycles from the profiled instruction mix (tools/summarize_prof.py), against
+                # 1024 SIMDs x 2.4 GHz x the LIVE launch time; beside it the same fraction at the clock the profiled pass held
+                "valu_slow_pipe_frac": round(pr["valu_slow_pipe_cycles"] / (1024 * 2.4e9 * live_s), 4),
+                "valu_slow_pipe_frac_at_measured_clock": round(pr["valu_slow_pipe_frac"], 4),
+                "valu_issue_frac": round(pr["valu_issue_cycles"] / (1024 * 2.4e9 * live_s), 4), "lane_util": round(pr["lane_util"], 4),
                 "hbm_bytes_per_launch": pr.get("hbm_bytes_per_launch"),
                 "hbm_frac": round(pr["hbm_bytes_per_launch"] / live_s / 8.0e12, 4) if pr.get("hbm_bytes_per_launch") else None})
         kernels.append(rec)
@@ -206,9 +228,9 @@ def main():
         achieved = (dom["hbm_bytes_per_launch"] / (dom["avg_launch_ms"] * 1e-3) / 1e9) if dom.get("hbm_bytes_per_launch") else dom["stream_GBps"]
         traffic = dom.get("hbm_bytes_per_launch")
     else:                                # traversal: bounded by VALU issue, not by HBM
-        bound, unit, peak = "valu", "G SIMD-cycles/s", 1024 * 2.4
+        bound, unit, peak = "valu", "G SIMD-cycles/s of the non-fp32 VALU pipe", 1024 * 2.4
         pr = prof_rec(dom["kernel"])
-        achieved = (pr["valu_issue_cycles"] / (dom["avg_launch_ms"] * 1e-3) / 1e9) if pr else None
+        achieved = (pr["valu_slow_pipe_cycles"] / (dom["avg_launch_ms"] * 1e-3) / 1e9) if pr else None
         traffic = dom.get("hbm_bytes_per_launch")
     roofline = {"bound": bound, "kernel": dom["kernel"], "achieved": round(achieved, 1) if achieved else None, "peak": peak, "unit": unit,
                 "frac": round(achieved / peak, 4) if achieved else None, "traffic": traffic,

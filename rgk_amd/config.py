@@ -10,6 +10,7 @@ import ctypes as C
 import json
 import math
 import os
+import re
 
 import numpy as np
 
@@ -515,6 +516,188 @@ class Config:
     def perform_post_check(self):
         """src/config.cpp:560-570: keys present but never read."""
         return self.root.unused()
+
+
+def _stoi(tok, what):
+    """std::stoi: optional sign + the leading decimal digits of the token (src/config.cpp uses it unguarded; a token without
+    digits makes the reference die with an uncaught std::invalid_argument -- here a ConfigFileException)."""
+    m = re.match(r"\s*[+-]?\d+", tok)
+    if not m:
+        raise ConfigFileException(f"Invalid {what}: '{tok}' is not an integer.")
+    return int(m.group(0))
+
+
+def _stof(tok, what):
+    m = re.match(r"\s*[+-]?(\d+\.?\d*([eE][+-]?\d+)?|\.\d+([eE][+-]?\d+)?|inf(inity)?|nan)", tok, re.I)
+    if not m:
+        raise ConfigFileException(f"Invalid {what}: '{tok}' is not a number.")
+    return f32(float(m.group(0)))
+
+
+class ConfigRTC:
+    """The reference's older line-based config format, ConfigRTC (src/config.cpp:27-258): nine fixed lines -- comment, model
+    file, output file, recursion level, `xres yres`, camera position, look-at, up vector, yview -- then option lines
+    (`L x y z r g b intensity [size]`, `multisample n`, `sky r g b [brightness]`, `lens`, `focus`, `bumpscale`, `clamp`,
+    `russian`, `rounds`, `reverse`, `brdf`, `thinglass`, `force_fresnell`; `#` starts a comment; unknown options warn).
+    Same interface as Config (get_camera / get_params / build_scene).  Fields keep the base class defaults of
+    src/config.hpp:31-42 where the file sets nothing: bumpscale 10, clamp 100000, russian -1 (no roulette), sky brightness 2."""
+
+    BRDFS = {"cooktorr": "cooktorr", "phong": "phong", "phong2": "phong2", "phongenergy": "phongenergy", "diffuse": "diffusecosine",
+             "diffuseuniform": "diffuseuniform", "ltc_beckmann": "ltc_beckmann", "ltc_ggx": "ltc_ggx"}
+
+    def __init__(self, path, text=None):
+        self.config_file_path = path
+        if text is None:
+            try:
+                text = open(path).read()
+            except OSError:
+                raise ConfigFileException("Failed to open config file ` " + path + " `.")
+        lines = text.split("\n")
+        if text.endswith("\n"):
+            lines = lines[:-1]           # std::getline: the final newline does not start another line
+        it = iter(lines)
+
+        def next_line():
+            # NEXT_LINE(): getline + trim, then "ends prematurely" unless the stream is still good -- it is not once a getline has
+            # run into the end of the file, i.e. when there was no line left or the line just read had no newline behind it
+            nonlocal pos
+            try:
+                ln = next(it)
+            except StopIteration:
+                raise ConfigFileException("Config file ends prematurely.")
+            pos += 1
+            if pos >= len(lines) and not text.endswith("\n"):
+                raise ConfigFileException("Config file ends prematurely.")
+            return ln.strip()
+        pos = 0
+        split = lambda ln: [t for t in ln.split(" ") if t != ""]
+        try:
+            first = next(it)
+            pos += 1
+        except StopIteration:
+            first = ""
+        self.comment = first.strip()
+        self.model_file = next_line()
+        self.output_file = next_line()
+        self.recursion_level = _stoi(next_line(), "recursion level") & 0xFFFFFFFF
+        vs = split(next_line())
+        if len(vs) != 2:
+            raise ConfigFileException("Invalid resolution format.")
+        self.xres, self.yres = _stoi(vs[0], "resolution"), _stoi(vs[1], "resolution")
+        if self.xres == 0 or self.yres == 0:
+            raise ConfigFileException("Invalid output image resolution.")
+
+        def vec(what):
+            v = split(next_line())
+            if len(v) != 3:
+                raise ConfigFileException(f"Invalid {what} format.")
+            return np.array([_stof(x, what) for x in v], dtype=f32)
+        self.camera_position, self.camera_lookat, self.camera_upvector = vec("VP"), vec("LA"), vec("UP")
+        self.yview = _stof(next_line(), "yview")
+        if self.yview <= 0.0 or self.yview >= 100.0:
+            raise ConfigFileException("Invalid yview value.")
+        # Config base-class defaults, src/config.hpp:31-42 and :77-85
+        self.multisample, self.bumpmap_scale, self.clamp, self.russian = 1, f32(10.0), f32(100000.0), f32(-1.0)
+        self.output_scale, self.render_rounds, self.render_minutes, self.force_fresnell, self.reverse = -1.0, 1, None, False, 0
+        self.lens_size, self.focus_plane, self.sky_color, self.sky_brightness = f32(0.0), f32(1.0), (0.0, 0.0, 0.0), f32(2.0)
+        self.lights, self.thinglass, self.brdf, self.warnings = [], [], "", []
+        for ln in it:
+            vs = split(ln.strip())
+            if not vs or vs[0][0] == "#":
+                continue
+            k, n = vs[0], len(vs)
+
+            def one(what):
+                if n != 2:
+                    raise ConfigFileException(f"Invalid {what} line.")
+                return vs[1]
+            if k == "L":
+                if n < 8 or n > 9:
+                    raise ConfigFileException("Invalid light line.")
+                pos3 = tuple(float(_stof(x, "light")) for x in vs[1:4])
+                col = tuple(float(f32(_stof(x, "light") / f32(255))) for x in vs[4:7])
+                self.lights.append(dict(pos=pos3, color=col, intensity=float(_stof(vs[7], "light")), size=float(_stof(vs[8], "light")) if n == 9 else 0.0))
+            elif k in ("multisample", "ms"):
+                self.multisample = _stoi(one("multisample"), "multisample")
+                if self.multisample == 0:
+                    raise ConfigFileException("Invalid multisample value.")
+            elif k in ("sky", "skycolor"):
+                if n < 4 or n > 5:
+                    raise ConfigFileException("Invalid sky color line.")
+                self.sky_color = tuple(float(f32(_stoi(x, "sky") / f32(255.0))) for x in vs[1:4])
+                if n == 5:
+                    self.sky_brightness = _stof(vs[4], "sky")
+            elif k in ("lens", "lenssize", "lens_size"):
+                self.lens_size = _stof(one("lens size"), "lens size")
+                if self.lens_size < 0:
+                    raise ConfigFileException("Lens size must be a poositive value.")
+            elif k in ("focus", "focus_plane", "focus_dist"):
+                self.focus_plane = _stof(one("focus plane"), "focus plane")
+                if self.focus_plane < 0:
+                    raise ConfigFileException("Focus plane must be a poositive value.")
+            elif k in ("bump_scale", "bumpmap_scale", "bump", "bumpscale"):
+                self.bumpmap_scale = _stof(one("bump scale config"), "bump scale")
+            elif k == "clamp":
+                self.clamp = _stof(one("clamp config"), "clamp")
+            elif k in ("russian", "roulette"):
+                self.russian = _stof(one("russian roulette config"), "russian")
+            elif k == "rounds":
+                self.render_rounds = _stoi(one("rounds config"), "rounds")
+            elif k == "reverse":
+                self.reverse = _stoi(one("reverse config"), "reverse")
+            elif k == "brdf":
+                b = one("brdf config")
+                if b not in self.BRDFS:
+                    raise ConfigFileException("Unknown BRDF type: " + b)
+                self.brdf = self.BRDFS[b]
+            elif k == "thinglass":
+                self.thinglass.append(one("thinglass config"))
+            elif k == "force_fresnell":
+                self.force_fresnell = _stoi(one("force_fresnell config"), "force_fresnell") == 1
+            else:
+                self.warnings.append(f"WARNING: Unrecognized option `{k}` in the config file.")
+
+    def get_camera(self, rotation=0.0):
+        """ConfigRTC::GetCamera (src/config.cpp:175-189): xview = yview * xres / yres."""
+        pos, lookat, up = self.camera_position, self.camera_lookat, self.camera_upvector
+        if rotation != 0.0:
+            from .scene import glm_rotate
+            R = glm_rotate(f32(rotation) * f32(2.0) * f32(math.pi), up)[:3, :3]
+            pos = lookat - (R @ (lookat - pos)).astype(f32)
+        xview = f32(f32(self.yview * f32(self.xres)) / f32(self.yres))
+        return camera_from_args(pos, lookat, up, self.yview, xview, self.xres, self.yres, self.focus_plane, self.lens_size)
+
+    get_params = Config.get_params
+
+    def build_scene(self, asset_dir=None, mesh_provider=None, builder=None):
+        """InstallMaterials (nothing), InstallScene (the model file with its own materials), InstallLights, InstallSky
+        (src/config.cpp:191-258)."""
+        sb = builder or SceneBuilder()
+        configdir = os.path.dirname(os.path.abspath(self.config_file_path))
+        modelfile = _resolve(configdir, self.model_file, asset_dir)
+        if modelfile is None:
+            if mesh_provider is None:
+                raise ConfigFileException(f'Unable to find model file "{os.path.join(configdir, self.model_file)}"')
+            mesh_provider(sb, self.model_file)
+        else:
+            sb.load_obj(modelfile, np.eye(4, dtype=f32), import_materials=True, override_materials=False)
+        for l in self.lights:
+            sb.add_point_light(l["pos"], l["color"], l["intensity"], l["size"])
+        sb.set_skybox_color(self.sky_color, float(self.sky_brightness))
+        return sb
+
+    def perform_post_check(self):
+        return list(self.warnings)
+
+
+def load_config(path, overrides=None):
+    """main.cpp:166-179: the config class by file extension (.rtc -> ConfigRTC, .json -> ConfigJSON)."""
+    ext = os.path.splitext(path)[1].lower()
+    if ext == ".rtc":
+        return ConfigRTC(path)
+    if ext == ".json":
+        return Config(path, overrides)
+    raise ConfigFileException(f'Config file format "{ext[1:]}" not recognized')
 
 
 def _resolve(configdir, rel, asset_dir):

@@ -16,6 +16,7 @@ All arithmetic is float32, evaluated in the order GLM evaluates it.
 import ctypes as C
 import math
 import os
+import re
 
 import numpy as np
 
@@ -155,6 +156,78 @@ def load_texture_file(path):
     return np.ascontiguousarray(a)  # uint8; decoded through gamma_lut() (RGK_TEX_RGB8)
 
 
+def load_hdr(path):
+    """FileTexture::CreateNewFromHDR (src/texture.cpp:294-321): a Radiance RGBE file through the decoder the reference vendors
+    (external/stb_image.h, stbi__hdr_load + stbi__hdr_convert, built STBI_ONLY_HDR) -> (h, w, 3) float32, top row first, no
+    gamma, no flip.  Header: the first line must be `#?RADIANCE`, some line `FORMAT=32-bit_rle_rgbe`, a blank line, then
+    `-Y <h> +X <w>`.  Scan lines are run-length encoded per channel when they start with 2, 2, <len hi < 128>, <len lo> (and
+    8 <= w < 32768); otherwise the file is flat RGBE from there on.  Pixel = byte * 2^(e - 136), or 0 when e == 0."""
+    b = open(path, "rb").read()
+    pos = 0
+
+    def token():
+        nonlocal pos
+        e = b.find(b"\n", pos)
+        if e < 0:
+            e = len(b)
+        t = b[pos:e]
+        pos = min(e + 1, len(b))
+        return t[:1023]   # STBI__HDR_BUFLEN
+    if token() != b"#?RADIANCE":
+        raise ValueError(f"Failed to load texture '{path}': not HDR")
+    valid = False
+    while True:
+        t = token()
+        if len(t) == 0:
+            break
+        if t == b"FORMAT=32-bit_rle_rgbe":
+            valid = True
+        if pos >= len(b):
+            break
+    if not valid:
+        raise ValueError(f"Failed to load texture '{path}': unsupported HDR format")
+    t = token()
+    m = re.match(rb"-Y ([+-]?\d+) *\+X ([+-]?\d+)", t)
+    if not m:
+        raise ValueError(f"Failed to load texture '{path}': unsupported HDR data layout")
+    h, w = int(m.group(1)), int(m.group(2))
+    data = np.frombuffer(b, dtype=np.uint8, offset=pos)
+    rgbe = np.zeros((h, w, 4), dtype=np.uint8)
+
+    def flat(start):
+        n = h * w * 4
+        if len(data) - start < n:
+            raise ValueError(f"Failed to load texture '{path}': truncated HDR data")
+        return data[start:start + n].reshape(h, w, 4)
+    if w < 8 or w >= 32768:
+        rgbe = flat(0)
+    else:
+        p = 0
+        for j in range(h):
+            if p + 4 > len(data):
+                raise ValueError(f"Failed to load texture '{path}': truncated HDR data")
+            c1, c2, ln = int(data[p]), int(data[p + 1]), int(data[p + 2])
+            if c1 != 2 or c2 != 2 or (ln & 0x80):
+                rgbe = flat(p)       # "not run-length encoded": stb restarts from pixel 0 with these very bytes, flat to the end
+                break
+            if ((ln << 8) | int(data[p + 3])) != w:
+                raise ValueError(f"Failed to load texture '{path}': corrupt HDR (invalid decoded scanline length)")
+            p += 4
+            for k in range(4):
+                i = 0
+                while i < w:
+                    count = int(data[p]); p += 1
+                    if count > 128:
+                        count -= 128
+                        rgbe[j, i:i + count, k] = data[p]; p += 1
+                    else:
+                        rgbe[j, i:i + count, k] = data[p:p + count]; p += count
+                    i += count
+    e = rgbe[..., 3].astype(np.int32)
+    f1 = np.where(e != 0, np.ldexp(np.float32(1.0), e - 136), np.float32(0.0)).astype(f32)
+    return np.ascontiguousarray(rgbe[..., :3].astype(f32) * f1[..., None])
+
+
 class SceneBuilder:
     def __init__(self):
         self.vertices, self.normals, self.tangents, self.texcoords = [], [], [], []
@@ -204,6 +277,8 @@ class SceneBuilder:
         if key in self.tex_by_path:
             return self.tex_by_path[key]
         try:
+            if os.path.splitext(path)[1].lower() == ".hdr":   # Scene::GetTexture dispatches on the extension, src/scene.cpp:258-270
+                return self.add_image_texture(key, load_hdr(path))
             return self.add_image_texture8(key, load_texture_file(path))
         except Exception as e:  # "Failed to load texture ..., ignoring it."
             if self.texture_fallback is not None:  # labelled proxy assets (rgk_amd.proxy)

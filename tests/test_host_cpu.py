@@ -206,6 +206,98 @@ def test_json_front_end_parses_every_shipped_scene_like_the_references_jsoncpp()
     assert n_comments >= 5   # the comment syntax is exercised (scenes/cornell-box.json and others carry comments)
 
 
+def _write_hdr(path, img_rgbe, rle, header_extra=b"", first=b"#?RADIANCE"):
+    """A Radiance file from (h, w, 4) RGBE bytes; rle: new-style per-channel run-length scan lines (runs and dumps)."""
+    h, w = img_rgbe.shape[:2]
+    out = [first + b"\n", header_extra, b"FORMAT=32-bit_rle_rgbe\n", b"\n", b"-Y %d +X %d\n" % (h, w)]
+    if not rle:
+        out.append(img_rgbe.tobytes())
+    else:
+        for j in range(h):
+            out.append(bytes([2, 2, w >> 8, w & 255]))
+            for k in range(4):
+                row, i = img_rgbe[j, :, k], 0
+                while i < w:
+                    run = 1
+                    while i + run < w and run < 127 and row[i + run] == row[i]:
+                        run += 1
+                    if run >= 3:
+                        out.append(bytes([128 + run, int(row[i])])); i += run
+                    else:
+                        n = 1
+                        while i + n < w and n < 128 and not (i + n + 2 < w and row[i + n] == row[i + n + 1] == row[i + n + 2]):
+                            n += 1
+                        out.append(bytes([n]) + row[i:i + n].tobytes()); i += n
+    open(path, "wb").write(b"".join(out))
+
+
+def test_hdr_decoder_equals_the_references_stb_image(tmp_path):
+    """f1 pinned: rgk_amd.scene.load_hdr against the decoder the reference vendors and calls (external/stb_image.h through
+    stbi_loadf, src/texture.cpp:294-321; compiled where it lies into oracle/_ref/stbi_ref) on run-length encoded, flat and
+    narrow Radiance files: the same floats bit for bit."""
+    from rgk_amd.scene import load_hdr
+    exe = os.path.join(ROOT, "oracle", "_ref", "stbi_ref")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/stbi_ref not built (reference absent on this box)")
+    rng = np.random.default_rng(9)
+    cases = []
+    for (h, w, rle) in ((17, 64, True), (9, 300, True), (5, 40, False), (6, 5, False), (3, 8, True)):
+        img = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        img[..., 3] = rng.integers(100, 150, (h, w))                # exponents around 128
+        img[1:3, : w // 2] = img[1, 0]                               # long runs
+        img[0, ::7, 3] = 0                                           # zero exponent -> black
+        if not rle:
+            img[0, 0, :3] = (200, 100, 50)                           # a first pixel that cannot be mistaken for a scan-line header
+        cases.append((img, rle))
+    for n, (img, rle) in enumerate(cases):
+        path = str(tmp_path / f"t{n}.hdr")
+        _write_hdr(path, img, rle, header_extra=b"# made by the test\nEXPOSURE=1.0\n")
+        out = str(tmp_path / f"t{n}.bin")
+        subprocess.run([exe, path, out], check=True)
+        b = open(out, "rb").read()
+        w, h, c = np.frombuffer(b, dtype=np.int32, count=3)
+        ref = np.frombuffer(b, dtype=np.float32, offset=12).reshape(h, w, c)
+        mine = load_hdr(path)
+        assert mine.shape == ref.shape == img.shape[:2] + (3,)
+        assert np.array_equal(mine.view(np.uint32), ref.view(np.uint32)), n
+    bad = str(tmp_path / "bad.hdr")
+    _write_hdr(bad, cases[0][0], True, first=b"#?RGBE")              # this stb version knows only #?RADIANCE
+    assert subprocess.run([exe, bad, str(tmp_path / "bad.bin")], capture_output=True).returncode != 0
+    with pytest.raises(ValueError):
+        load_hdr(bad)
+
+
+def test_rtc_config_format(tmp_path):
+    """ConfigRTC (src/config.cpp:27-258): the reference's line-based format.  Its only shipped .rtc file holds JSON
+    (scenes/sponza.rtc) and is refused like the reference refuses it; a well-formed file parses to the same
+    fields, with the base-class defaults where it is silent."""
+    from rgk_amd.config import ConfigRTC, load_config
+    p = tmp_path / "scene.rtc"
+    p.write_text("a comment\ncubes/cube3.obj\nout.exr\n7\n640 480\n1.5 2.85 -4.0\n1.0 1.0 1.0\n0 1 0\n1.2\n# c\n"
+                 "L 3.0 6.0 -2.0 255 255 200 400.0 0.4\nms 16\nsky 145 200 235 0.3\nclamp 10\nroulette 0.6\nbrdf diffuse\nreverse 2\nbogus 1\n")
+    c = load_config(str(p))
+    assert isinstance(c, ConfigRTC)
+    assert (c.comment, c.model_file, c.output_file, c.recursion_level, c.xres, c.yres) == ("a comment", "cubes/cube3.obj", "out.exr", 7, 640, 480)
+    assert c.multisample == 16 and c.reverse == 2 and c.brdf == "diffusecosine" and float(c.clamp) == 10.0 and abs(float(c.russian) - 0.6) < 1e-7
+    assert float(c.bumpmap_scale) == 10.0 and c.render_rounds == 1 and float(c.sky_brightness) == pytest.approx(0.3)      # bumpscale: base-class default
+    assert c.lights == [dict(pos=(3.0, 6.0, -2.0), color=(1.0, 1.0, float(np.float32(200) / np.float32(255))), intensity=400.0, size=float(np.float32(0.4)))]
+    assert c.perform_post_check() == ["WARNING: Unrecognized option `bogus` in the config file."]
+    cam = c.get_camera()
+    assert cam.ctor["yview"] == pytest.approx(1.2) and cam.ctor["xview"] == pytest.approx(1.2 * 640 / 480)
+    prm = c.get_params()
+    assert (prm.xres, prm.yres, prm.multisample, prm.depth, prm.reverse) == (640, 480, 16, 7, 2)
+    short = tmp_path / "short.rtc"
+    short.write_text("c\nm.obj\no.exr\n3\n64 48")
+    with pytest.raises(ConfigFileException, match="prematurely"):
+        load_config(str(short))
+    ref = os.path.join(REF_DIR, "scenes", "sponza.rtc")
+    if os.path.exists(ref):
+        with pytest.raises(ConfigFileException):
+            load_config(ref)                                          # JSON inside a .rtc: std::stoi of `"output-width": 1200,` (F7)
+    with pytest.raises(ConfigFileException, match="not recognized"):
+        load_config(str(tmp_path / "x.txt"))
+
+
 def test_config_errors(tmp_path):
     def cfg(d):
         p = tmp_path / "e.json"

@@ -47,6 +47,40 @@ __global__ __launch_bounds__(256, 8) void k_class(unsigned long long* stamps, fl
         if (KIND == 23) asm volatile("v_add_f64 %0, %8, %9\nv_add_f64 %1, %8, %9\nv_add_f64 %2, %8, %9\nv_add_f64 %3, %8, %9\nv_add_f64 %4, %8, %9\nv_add_f64 %5, %8, %9\nv_add_f64 %6, %8, %9\nv_add_f64 %7, %8, %9" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5), "+v"(e6), "+v"(e7) : "v"(t0d), "v"(t1d));
         if (KIND == 24) asm volatile("v_pk_fma_f32 %0, %8, %9, %8\nv_pk_fma_f32 %1, %8, %9, %8\nv_pk_fma_f32 %2, %8, %9, %8\nv_pk_fma_f32 %3, %8, %9, %8\nv_pk_fma_f32 %4, %8, %9, %8\nv_pk_fma_f32 %5, %8, %9, %8\nv_pk_fma_f32 %6, %8, %9, %8\nv_pk_fma_f32 %7, %8, %9, %8" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5), "+v"(e6), "+v"(e7) : "v"(t0d), "v"(t1d));
         if (KIND == 25) asm volatile("v_rcp_f64_e32 %0, %8\nv_rcp_f64_e32 %1, %8\nv_rcp_f64_e32 %2, %8\nv_rcp_f64_e32 %3, %8\nv_rcp_f64_e32 %4, %8\nv_rcp_f64_e32 %5, %8\nv_rcp_f64_e32 %6, %8\nv_rcp_f64_e32 %7, %8" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5), "+v"(e6), "+v"(e7) : "v"(t0d), "v"(t1d));
+        if (KIND == 200) asm volatile("v_xor_b32_e32 %0, %8, %9\nv_xor_b32_e32 %1, %8, %9\nv_xor_b32_e32 %2, %8, %9\nv_xor_b32_e32 %3, %8, %9\nv_xor_b32_e32 %4, %8, %9\nv_xor_b32_e32 %5, %8, %9\nv_xor_b32_e32 %6, %8, %9\nv_xor_b32_e32 %7, %8, %9" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
+        if (KIND == 201) asm volatile("v_or_b32_e32 %0, %8, %9\nv_or_b32_e32 %1, %8, %9\nv_or_b32_e32 %2, %8, %9\nv_or_b32_e32 %3, %8, %9\nv_or_b32_e32 %4, %8, %9\nv_or_b32_e32 %5, %8, %9\nv_or_b32_e32 %6, %8, %9\nv_or_b32_e32 %7, %8, %9" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
+        if (KIND == 202) asm volatile("v_not_b32_e32 %0, %8\nv_not_b32_e32 %1, %8\nv_not_b32_e32 %2, %8\nv_not_b32_e32 %3, %8\nv_not_b32_e32 %4, %8\nv_not_b32_e32 %5, %8\nv_not_b32_e32 %6, %8\nv_not_b32_e32 %7, %8" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
+        if (KIND == 203) asm volatile("v_bfi_b32 %0, %8, %9, %8\nv_bfi_b32 %1, %8, %9, %8\nv_bfi_b32 %2, %8, %9, %8\nv_bfi_b32 %3, %8, %9, %8\nv_bfi_b32 %4, %8, %9, %8\nv_bfi_b32 %5, %8, %9, %8\nv_bfi_b32 %6, %8, %9, %8\nv_bfi_b32 %7, %8, %9, %8" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
+        if (KIND == 204) asm volatile("v_sub_u32_e32 %0, %8, %9\nv_sub_u32_e32 %1, %8, %9\nv_sub_u32_e32 %2, %8, %9\nv_sub_u32_e32 %3, %8, %9\nv_sub_u32_e32 %4, %8, %9\nv_sub_u32_e32 %5, %8, %9\nv_sub_u32_e32 %6, %8, %9\nv_sub_u32_e32 %7, %8, %9" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
+        if (KIND == 205) asm volatile("v_lshrrev_b32_e32 %0, 8, %8\nv_lshrrev_b32_e32 %1, 8, %8\nv_lshrrev_b32_e32 %2, 8, %8\nv_lshrrev_b32_e32 %3, 8, %8\nv_lshrrev_b32_e32 %4, 8, %8\nv_lshrrev_b32_e32 %5, 8, %8\nv_lshrrev_b32_e32 %6, 8, %8\nv_lshrrev_b32_e32 %7, 8, %8" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
+        if (KIND == 206) asm volatile("v_ashrrev_i32_e32 %0, 8, %8\nv_ashrrev_i32_e32 %1, 8, %8\nv_ashrrev_i32_e32 %2, 8, %8\nv_ashrrev_i32_e32 %3, 8, %8\nv_ashrrev_i32_e32 %4, 8, %8\nv_ashrrev_i32_e32 %5, 8, %8\nv_ashrrev_i32_e32 %6, 8, %8\nv_ashrrev_i32_e32 %7, 8, %8" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
+        if (KIND == 207) asm volatile("v_min_u32_e32 %0, %8, %9\nv_min_u32_e32 %1, %8, %9\nv_min_u32_e32 %2, %8, %9\nv_min_u32_e32 %3, %8, %9\nv_min_u32_e32 %4, %8, %9\nv_min_u32_e32 %5, %8, %9\nv_min_u32_e32 %6, %8, %9\nv_min_u32_e32 %7, %8, %9" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
+        if (KIND == 208) asm volatile("v_max_i32_e32 %0, %8, %9\nv_max_i32_e32 %1, %8, %9\nv_max_i32_e32 %2, %8, %9\nv_max_i32_e32 %3, %8, %9\nv_max_i32_e32 %4, %8, %9\nv_max_i32_e32 %5, %8, %9\nv_max_i32_e32 %6, %8, %9\nv_max_i32_e32 %7, %8, %9" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
+        if (KIND == 209) asm volatile("v_med3_f32 %0, %8, %9, %8\nv_med3_f32 %1, %8, %9, %8\nv_med3_f32 %2, %8, %9, %8\nv_med3_f32 %3, %8, %9, %8\nv_med3_f32 %4, %8, %9, %8\nv_med3_f32 %5, %8, %9, %8\nv_med3_f32 %6, %8, %9, %8\nv_med3_f32 %7, %8, %9, %8" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
+        if (KIND == 210) asm volatile("v_add3_u32 %0, %8, %9, %8\nv_add3_u32 %1, %8, %9, %8\nv_add3_u32 %2, %8, %9, %8\nv_add3_u32 %3, %8, %9, %8\nv_add3_u32 %4, %8, %9, %8\nv_add3_u32 %5, %8, %9, %8\nv_add3_u32 %6, %8, %9, %8\nv_add3_u32 %7, %8, %9, %8" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
+        if (KIND == 211) asm volatile("v_mad_u32_u24 %0, %8, %9, %8\nv_mad_u32_u24 %1, %8, %9, %8\nv_mad_u32_u24 %2, %8, %9, %8\nv_mad_u32_u24 %3, %8, %9, %8\nv_mad_u32_u24 %4, %8, %9, %8\nv_mad_u32_u24 %5, %8, %9, %8\nv_mad_u32_u24 %6, %8, %9, %8\nv_mad_u32_u24 %7, %8, %9, %8" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
+        if (KIND == 212) asm volatile("v_mul_u32_u24_e32 %0, %8, %9\nv_mul_u32_u24_e32 %1, %8, %9\nv_mul_u32_u24_e32 %2, %8, %9\nv_mul_u32_u24_e32 %3, %8, %9\nv_mul_u32_u24_e32 %4, %8, %9\nv_mul_u32_u24_e32 %5, %8, %9\nv_mul_u32_u24_e32 %6, %8, %9\nv_mul_u32_u24_e32 %7, %8, %9" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
+        if (KIND == 213) asm volatile("v_fmac_f32_e32 %0, %8, %9\nv_fmac_f32_e32 %1, %8, %9\nv_fmac_f32_e32 %2, %8, %9\nv_fmac_f32_e32 %3, %8, %9\nv_fmac_f32_e32 %4, %8, %9\nv_fmac_f32_e32 %5, %8, %9\nv_fmac_f32_e32 %6, %8, %9\nv_fmac_f32_e32 %7, %8, %9" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
+        if (KIND == 214) asm volatile("v_sub_f32_e32 %0, %8, %9\nv_sub_f32_e32 %1, %8, %9\nv_sub_f32_e32 %2, %8, %9\nv_sub_f32_e32 %3, %8, %9\nv_sub_f32_e32 %4, %8, %9\nv_sub_f32_e32 %5, %8, %9\nv_sub_f32_e32 %6, %8, %9\nv_sub_f32_e32 %7, %8, %9" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
+        if (KIND == 215) asm volatile("v_fract_f32_e32 %0, %8\nv_fract_f32_e32 %1, %8\nv_fract_f32_e32 %2, %8\nv_fract_f32_e32 %3, %8\nv_fract_f32_e32 %4, %8\nv_fract_f32_e32 %5, %8\nv_fract_f32_e32 %6, %8\nv_fract_f32_e32 %7, %8" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
+        if (KIND == 216) asm volatile("v_floor_f32_e32 %0, %8\nv_floor_f32_e32 %1, %8\nv_floor_f32_e32 %2, %8\nv_floor_f32_e32 %3, %8\nv_floor_f32_e32 %4, %8\nv_floor_f32_e32 %5, %8\nv_floor_f32_e32 %6, %8\nv_floor_f32_e32 %7, %8" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
+        if (KIND == 217) asm volatile("v_trunc_f32_e32 %0, %8\nv_trunc_f32_e32 %1, %8\nv_trunc_f32_e32 %2, %8\nv_trunc_f32_e32 %3, %8\nv_trunc_f32_e32 %4, %8\nv_trunc_f32_e32 %5, %8\nv_trunc_f32_e32 %6, %8\nv_trunc_f32_e32 %7, %8" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
+        if (KIND == 218) asm volatile("v_rndne_f32_e32 %0, %8\nv_rndne_f32_e32 %1, %8\nv_rndne_f32_e32 %2, %8\nv_rndne_f32_e32 %3, %8\nv_rndne_f32_e32 %4, %8\nv_rndne_f32_e32 %5, %8\nv_rndne_f32_e32 %6, %8\nv_rndne_f32_e32 %7, %8" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
+        if (KIND == 219) asm volatile("v_cvt_u32_f32_e32 %0, %8\nv_cvt_u32_f32_e32 %1, %8\nv_cvt_u32_f32_e32 %2, %8\nv_cvt_u32_f32_e32 %3, %8\nv_cvt_u32_f32_e32 %4, %8\nv_cvt_u32_f32_e32 %5, %8\nv_cvt_u32_f32_e32 %6, %8\nv_cvt_u32_f32_e32 %7, %8" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
+        if (KIND == 220) asm volatile("v_cvt_f32_i32_e32 %0, %8\nv_cvt_f32_i32_e32 %1, %8\nv_cvt_f32_i32_e32 %2, %8\nv_cvt_f32_i32_e32 %3, %8\nv_cvt_f32_i32_e32 %4, %8\nv_cvt_f32_i32_e32 %5, %8\nv_cvt_f32_i32_e32 %6, %8\nv_cvt_f32_i32_e32 %7, %8" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
+        if (KIND == 221) asm volatile("v_ldexp_f32 %0, %8, 3\nv_ldexp_f32 %1, %8, 3\nv_ldexp_f32 %2, %8, 3\nv_ldexp_f32 %3, %8, 3\nv_ldexp_f32 %4, %8, 3\nv_ldexp_f32 %5, %8, 3\nv_ldexp_f32 %6, %8, 3\nv_ldexp_f32 %7, %8, 3" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
+        if (KIND == 222) asm volatile("v_mul_hi_u32 %0, %8, %9\nv_mul_hi_u32 %1, %8, %9\nv_mul_hi_u32 %2, %8, %9\nv_mul_hi_u32 %3, %8, %9\nv_mul_hi_u32 %4, %8, %9\nv_mul_hi_u32 %5, %8, %9\nv_mul_hi_u32 %6, %8, %9\nv_mul_hi_u32 %7, %8, %9" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
+        if (KIND == 223) asm volatile("v_cndmask_b32_e32 %0, %8, %9, vcc\nv_cndmask_b32_e32 %1, %8, %9, vcc\nv_cndmask_b32_e32 %2, %8, %9, vcc\nv_cndmask_b32_e32 %3, %8, %9, vcc\nv_cndmask_b32_e32 %4, %8, %9, vcc\nv_cndmask_b32_e32 %5, %8, %9, vcc\nv_cndmask_b32_e32 %6, %8, %9, vcc\nv_cndmask_b32_e32 %7, %8, %9, vcc" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1) : "vcc");
+        if (KIND == 224) asm volatile("v_alignbit_b32 %0, %8, %9, 8\nv_alignbit_b32 %1, %8, %9, 8\nv_alignbit_b32 %2, %8, %9, 8\nv_alignbit_b32 %3, %8, %9, 8\nv_alignbit_b32 %4, %8, %9, 8\nv_alignbit_b32 %5, %8, %9, 8\nv_alignbit_b32 %6, %8, %9, 8\nv_alignbit_b32 %7, %8, %9, 8" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
+        if (KIND == 225) asm volatile("v_and_or_b32 %0, %8, %9, %8\nv_and_or_b32 %1, %8, %9, %8\nv_and_or_b32 %2, %8, %9, %8\nv_and_or_b32 %3, %8, %9, %8\nv_and_or_b32 %4, %8, %9, %8\nv_and_or_b32 %5, %8, %9, %8\nv_and_or_b32 %6, %8, %9, %8\nv_and_or_b32 %7, %8, %9, %8" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
+        if (KIND == 226) asm volatile("v_lshl_or_b32 %0, %8, 8, %9\nv_lshl_or_b32 %1, %8, 8, %9\nv_lshl_or_b32 %2, %8, 8, %9\nv_lshl_or_b32 %3, %8, 8, %9\nv_lshl_or_b32 %4, %8, 8, %9\nv_lshl_or_b32 %5, %8, 8, %9\nv_lshl_or_b32 %6, %8, 8, %9\nv_lshl_or_b32 %7, %8, 8, %9" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
+        if (KIND == 227) asm volatile("v_min_f32_e32 %0, %8, %9\nv_min_f32_e32 %1, %8, %9\nv_min_f32_e32 %2, %8, %9\nv_min_f32_e32 %3, %8, %9\nv_min_f32_e32 %4, %8, %9\nv_min_f32_e32 %5, %8, %9\nv_min_f32_e32 %6, %8, %9\nv_min_f32_e32 %7, %8, %9" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
+        if (KIND == 228) asm volatile("v_fma_f32 %0, |%8|, -%9, %8\nv_fma_f32 %1, |%8|, -%9, %8\nv_fma_f32 %2, |%8|, -%9, %8\nv_fma_f32 %3, |%8|, -%9, %8\nv_fma_f32 %4, |%8|, -%9, %8\nv_fma_f32 %5, |%8|, -%9, %8\nv_fma_f32 %6, |%8|, -%9, %8\nv_fma_f32 %7, |%8|, -%9, %8" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
+        if (KIND == 229) asm volatile("v_add_f32_e64 %0, |%8|, %9\nv_add_f32_e64 %1, |%8|, %9\nv_add_f32_e64 %2, |%8|, %9\nv_add_f32_e64 %3, |%8|, %9\nv_add_f32_e64 %4, |%8|, %9\nv_add_f32_e64 %5, |%8|, %9\nv_add_f32_e64 %6, |%8|, %9\nv_add_f32_e64 %7, |%8|, %9" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
+        if (KIND == 230) asm volatile("v_mul_f32_e64 %0, %8, %9 mul:2\nv_mul_f32_e64 %1, %8, %9 mul:2\nv_mul_f32_e64 %2, %8, %9 mul:2\nv_mul_f32_e64 %3, %8, %9 mul:2\nv_mul_f32_e64 %4, %8, %9 mul:2\nv_mul_f32_e64 %5, %8, %9 mul:2\nv_mul_f32_e64 %6, %8, %9 mul:2\nv_mul_f32_e64 %7, %8, %9 mul:2" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
+        if (KIND == 231) asm volatile("v_cvt_f32_ubyte0_e32 %0, %8\nv_cvt_f32_ubyte0_e32 %1, %8\nv_cvt_f32_ubyte0_e32 %2, %8\nv_cvt_f32_ubyte0_e32 %3, %8\nv_cvt_f32_ubyte0_e32 %4, %8\nv_cvt_f32_ubyte0_e32 %5, %8\nv_cvt_f32_ubyte0_e32 %6, %8\nv_cvt_f32_ubyte0_e32 %7, %8" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
+        if (KIND == 232) asm volatile("v_cvt_off_f32_i4_e32 %0, %8\nv_cvt_off_f32_i4_e32 %1, %8\nv_cvt_off_f32_i4_e32 %2, %8\nv_cvt_off_f32_i4_e32 %3, %8\nv_cvt_off_f32_i4_e32 %4, %8\nv_cvt_off_f32_i4_e32 %5, %8\nv_cvt_off_f32_i4_e32 %6, %8\nv_cvt_off_f32_i4_e32 %7, %8" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
+        if (KIND == 233) asm volatile("v_mov_b32_dpp %0, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\nv_mov_b32_dpp %1, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\nv_mov_b32_dpp %2, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\nv_mov_b32_dpp %3, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\nv_mov_b32_dpp %4, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\nv_mov_b32_dpp %5, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\nv_mov_b32_dpp %6, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\nv_mov_b32_dpp %7, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
         // mixed streams: does a 4-cycle class overlap with fp32 fma issued beside it?  KIND 100: alternating inside every wave;
         // KIND 101: odd waves issue only fma, even waves only cvt (the same number of instructions per wave either way)
         if (KIND == 100) asm volatile("v_fma_f32 %0, %8, %9, %8\nv_cvt_f32_ubyte1_e32 %1, %8\nv_fma_f32 %2, %8, %9, %8\nv_cvt_f32_ubyte1_e32 %3, %8\nv_fma_f32 %4, %8, %9, %8\nv_cvt_f32_ubyte1_e32 %5, %8\nv_fma_f32 %6, %8, %9, %8\nv_cvt_f32_ubyte1_e32 %7, %8" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(s0), "v"(s1));
@@ -114,6 +148,40 @@ int main() {
     if (run<23>("v_add_f64")) return 1;
     if (run<24>("v_pk_fma_f32")) return 1;
     if (run<25>("v_rcp_f64")) return 1;
+    if (run<200>("v_xor_b32")) return 1;
+    if (run<201>("v_or_b32")) return 1;
+    if (run<202>("v_not_b32")) return 1;
+    if (run<203>("v_bfi_b32")) return 1;
+    if (run<204>("v_sub_u32")) return 1;
+    if (run<205>("v_lshrrev_b32")) return 1;
+    if (run<206>("v_ashrrev_i32")) return 1;
+    if (run<207>("v_min_u32")) return 1;
+    if (run<208>("v_max_i32")) return 1;
+    if (run<209>("v_med3_f32")) return 1;
+    if (run<210>("v_add3_u32")) return 1;
+    if (run<211>("v_mad_u32_u24")) return 1;
+    if (run<212>("v_mul_u32_u24")) return 1;
+    if (run<213>("v_fmac_f32")) return 1;
+    if (run<214>("v_sub_f32")) return 1;
+    if (run<215>("v_fract_f32")) return 1;
+    if (run<216>("v_floor_f32")) return 1;
+    if (run<217>("v_trunc_f32")) return 1;
+    if (run<218>("v_rndne_f32")) return 1;
+    if (run<219>("v_cvt_u32_f32")) return 1;
+    if (run<220>("v_cvt_f32_i32")) return 1;
+    if (run<221>("v_ldexp_f32")) return 1;
+    if (run<222>("v_mul_hi_u32")) return 1;
+    if (run<223>("v_cndmask_b32_e32")) return 1;
+    if (run<224>("v_alignbit_b32")) return 1;
+    if (run<225>("v_and_or_b32")) return 1;
+    if (run<226>("v_lshl_or_b32")) return 1;
+    if (run<227>("v_min_f32")) return 1;
+    if (run<228>("v_fma_f32 |abs| -neg")) return 1;
+    if (run<229>("v_add_f32 sdwa? e64 abs")) return 1;
+    if (run<230>("v_mul_f32 omod")) return 1;
+    if (run<231>("v_cvt_f32_ubyte0")) return 1;
+    if (run<232>("v_cvt_off_f32_i4")) return 1;
+    if (run<233>("v_mov_b32 dpp quad")) return 1;
     if (run<100>("4 fma + 4 cvt / wave")) return 1;
     if (run<101>("fma waves | cvt waves")) return 1;
     if (run<102>("4 fma + 4 sel/max")) return 1;

@@ -11,14 +11,24 @@ under profiles/ -- the evidence bench.py's `roofline` object points at.
                                     the VALU ISSUE time it implies under the measured issue costs below, the shader cycles the
                                     kernel had (GRBM_GUI_ACTIVE / 8 XCDs, same pass), lane utilisation, HBM bytes per launch
 
-VALU issue costs, shader cycles one SIMD spends per wave64 instruction with 4 waves per SIMD issuing nothing else
-(tools/micro/valu_peak.hip on MI355X, profiles/<tag>_valu_issue_costs.txt): only fp32 add / mul / fma run at the SIMD-32
-rate of 2; everything else measured -- conversions, min / max / max3, compares, selects, integer and bit operations, moves,
-fp64 add / mul / fma, packed fp32 -- takes 4; transcendentals (rcp, sqrt, ...) 8; v_rcp_f64 16.
-    issue_cycles = 2 (ADD_F32 + MUL_F32 + FMA_F32) + 8 TRANS_F32 + 4 (everything else)
-    valu_issue_frac = issue_cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)          both from the same counter pass
-    lane_util       = SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU)
-    valu_lane_frac  = valu_issue_frac x lane_util      (useful lane-cycles over available lane-cycles)
+VALU model (tools/micro/valu_peak.hip on MI355X, profiles/<tag>_valu_issue_costs.txt; wall time x measured clock, 8 waves per
+SIMD, independent registers): a wave64 instruction costs one SIMD
+    ~2.4 cycles  fp32 add / sub / mul / fma / fmac (modifiers included), v_mov_b32              -- the SIMD-32 rate
+    ~3.2 cycles  32-bit integer add / sub, and / or / xor / not, right shifts
+    ~4.3 cycles  everything else measured: conversions, min / max / max3 / med3, compares, selects, bfe / bfi / perm, left
+                 shifts, lshl_add / lshl_or / and_or, integer multiplies, floor / trunc / fract, ldexp, div_scale / fmas / fixup,
+                 dpp moves, fp64 add / mul / fma, packed fp32
+    ~9.2 cycles  transcendentals (rcp, sqrt, ...);  ~16.4 v_rcp_f64
+and fp32 arithmetic OVERLAPS with the slower class (4 fma + 4 cvt interleaved: 2.5 cycles per instruction, not 3.4): a SIMD
+has an issue port (2 cycles per instruction) and a slower, 16-lane-wide path that the non-fp32 instructions occupy for 4.
+So two ceilings per kernel, both from the same counter pass and both <= 1 by construction of the model (nominal costs 2 / 3 / 4 / 8):
+    valu_issue_frac     = 2 x SQ_INSTS_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)
+    valu_slow_pipe_frac = (4 x (other + fp64) + 3 x int32/64 + 8 x trans) / (1024 x GRBM_GUI_ACTIVE / 8),
+                          other = SQ_INSTS_VALU - fp32 add/mul/fma - trans - fp64 - int   (conversions, compares, selects, min/max, ...)
+    lane_util           = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU-weighted instructions) ~ SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU)
+The traversal kernels sit at 0.92-0.96 of the slow-pipe ceiling: they are VALU-bound on the instructions that are NOT fp32
+arithmetic (byte -> float conversions of the quantised planes, min / max of the slab test, the selects and compares of the
+child sort), with 54-78 % of the lanes doing useful work.
 """
 import collections
 import csv
@@ -29,7 +39,7 @@ import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 N_SIMD, N_XCD, HBM_PEAK = 1024, 8, 8.0e12
-COST = {"f32_add_mul_fma": 2, "trans_f32": 8, "other": 4}
+COST = {"issue_per_instruction": 2, "slow_other_and_fp64": 4, "slow_int": 3, "slow_trans": 8}
 
 
 def short(name):
@@ -101,15 +111,17 @@ def main():
         trans = per("SQ_INSTS_VALU_TRANS_F32")
         f64 = per("SQ_INSTS_VALU_ADD_F64") + per("SQ_INSTS_VALU_MUL_F64") + per("SQ_INSTS_VALU_FMA_F64")
         ints = per("SQ_INSTS_VALU_INT32") + per("SQ_INSTS_VALU_INT64")
-        other = max(insts - fast - trans, 0.0)
-        issue = COST["f32_add_mul_fma"] * fast + COST["trans_f32"] * trans + COST["other"] * other
+        other = max(insts - fast - trans - f64 - ints, 0.0)
+        issue = COST["issue_per_instruction"] * insts
+        slow = COST["slow_other_and_fp64"] * (other + f64) + COST["slow_int"] * ints + COST["slow_trans"] * trans
         cyc = per("GRBM_GUI_ACTIVE") / N_XCD
         lane = per("SQ_THREAD_CYCLES_VALU") / (64.0 * insts) if insts else 0.0
         rec = {"launches_profiled": m["SQ_INSTS_VALU"][1], "avg_ms": round(stats[k]["avg_ms"], 4), "pct_of_gpu_time": stats[k]["pct"],
-               "insts_valu": insts, "insts_f32_add_mul_fma": fast, "insts_trans_f32": trans, "insts_f64": f64, "insts_int": ints,
-               "valu_issue_cycles": issue, "shader_cycles": cyc,
-               "valu_issue_frac": round(issue / (N_SIMD * cyc), 4) if cyc else None, "lane_util": round(lane, 4),
-               "valu_lane_frac": round(issue / (N_SIMD * cyc) * lane, 4) if cyc else None}
+               "insts_valu": insts, "insts_f32_add_mul_fma": fast, "insts_trans_f32": trans, "insts_f64": f64, "insts_int": ints, "insts_other": other,
+               "valu_issue_cycles": issue, "valu_slow_pipe_cycles": slow, "shader_cycles": cyc,
+               "valu_issue_frac": round(issue / (N_SIMD * cyc), 4) if cyc else None,
+               "valu_slow_pipe_frac": round(slow / (N_SIMD * cyc), 4) if cyc else None, "lane_util": round(min(lane, 1.0), 4),
+               "valu_lane_frac": round(slow / (N_SIMD * cyc) * min(lane, 1.0), 4) if cyc else None}
         if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
             b = 2.0 * per("FETCH_SIZE") * 1024 + per("WRITE_SIZE") * 1024
             rec["hbm_bytes_per_launch"] = b
@@ -118,7 +130,7 @@ def main():
         roof["kernels"][k] = rec
     json.dump(roof, open(os.path.join(out, f"{tag}_roofline.json"), "w"), indent=1)
     for k, r in roof["kernels"].items():
-        print(f"{k:34s} {r['avg_ms']:9.3f} ms  valu_issue {r['valu_issue_frac']}  lane {r['lane_util']}  hbm {r.get('hbm_frac')}")
+        print(f"{k:34s} {r['avg_ms']:9.3f} ms  valu issue {r['valu_issue_frac']} slow pipe {r['valu_slow_pipe_frac']}  lane {r['lane_util']}  hbm {r.get('hbm_frac')}")
     micro = os.path.join(ROOT, "gpurun_out", "r2_valu_peak.txt")
     if os.path.exists(micro):
         open(os.path.join(out, f"{tag}_valu_issue_costs.txt"), "w").write(open(micro).read())
