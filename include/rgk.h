@@ -215,6 +215,17 @@ typedef struct rgk_hit {
     float a, b, c; /* Intersection::a,b,c  (c'=1-alpha-beta, alpha, beta) scene_intersect.cpp:280-283 */
 } rgk_hit;
 
+/* Progress of the round a scene is rendering, for a monitor thread (the reference's FrameMonitorThread reads pixels_done /
+ * rays_done every 100 ms, src/render_driver.cpp:49-139).  Fed from the device's side of the stream: a host callback behind every
+ * bounce of every pass bumps `stage`.  pixels_done of the reference = round_pixels * stage / stages (+ round_pixels per finished round). */
+typedef struct rgk_progress {
+    uint32_t stage, stages;      /* bounces finished / bounces in the round (over all passes); stage == stages: round done */
+    uint32_t rounds;             /* rounds this scene has finished since it was created                                    */
+    uint32_t busy;               /* 1 while a round is in flight                                                            */
+    uint64_t round_pixels;       /* pixels of the round in flight (or of the last one)                                      */
+    uint64_t round_paths;        /* pixels * multisample                                                                     */
+} rgk_progress;
+
 typedef struct rgk_scene rgk_scene;
 
 const char *rgk_last_error(void);
@@ -224,6 +235,9 @@ int rgk_device_count(void);
 int rgk_scene_create(const rgk_scene_desc *desc, int device, rgk_scene **out);
 void rgk_scene_destroy(rgk_scene *scene);
 int rgk_scene_get_info(const rgk_scene *scene, rgk_scene_info *out);
+
+/* Callable from ANY thread while another thread is inside rgk_render_round*: never blocks, touches no device state. */
+int rgk_scene_get_progress(const rgk_scene *scene, rgk_progress *out);
 
 /* GenerateTaskList, src/render_driver.cpp:30-46.  Tiles of tile_size, sorted by
  * distance of the tile midpoint to (mid_x, mid_y); ties broken by (y0, x0)

@@ -100,6 +100,11 @@ class SceneInfo(C.Structure):
                 ("max_depth", C.c_uint32), ("n_leaf_refs", C.c_uint32)]
 
 
+class Progress(C.Structure):
+    _fields_ = [("stage", C.c_uint32), ("stages", C.c_uint32), ("rounds", C.c_uint32), ("busy", C.c_uint32),
+                ("round_pixels", C.c_uint64), ("round_paths", C.c_uint64)]
+
+
 class Hit(C.Structure):
     _fields_ = [("t", C.c_float), ("tri", C.c_int32), ("a", C.c_float), ("b", C.c_float),
                 ("c", C.c_float)]
@@ -107,7 +112,7 @@ class Hit(C.Structure):
 
 # every symbol include/rgk.h declares (tests check the .so exports all of them)
 EXPORTS = ["rgk_last_error", "rgk_device_count", "rgk_scene_create", "rgk_scene_destroy",
-           "rgk_scene_get_info", "rgk_generate_task_list", "rgk_camera_init", "rgk_render_round",
+           "rgk_scene_get_info", "rgk_scene_get_progress", "rgk_generate_task_list", "rgk_camera_init", "rgk_render_round",
            "rgk_render_round_device", "rgk_trace_closest", "rgk_trace_visibility",
            "rgk_bxdf_value", "rgk_bxdf_sample", "rgk_texture_sample",
            "rgk_libm_eval", "rgk_sampler_eval", "rgk_output_normalize", "rgk_output_write_exr", "rgk_float_to_half",
@@ -125,6 +130,7 @@ def _bind(lib):
     lib.rgk_scene_destroy.argtypes = [C.c_void_p]
     lib.rgk_scene_destroy.restype = None
     lib.rgk_scene_get_info.argtypes = [C.c_void_p, _p(SceneInfo)]
+    lib.rgk_scene_get_progress.argtypes = [C.c_void_p, _p(Progress)]
     lib.rgk_generate_task_list.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float,
                                            C.c_uint32, C.c_uint32, _p(Tile), _p(C.c_uint32)]
     lib.rgk_camera_init.argtypes = [_p(Camera), f3, f3, f3, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_float, C.c_float]

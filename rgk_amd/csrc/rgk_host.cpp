@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -383,6 +384,9 @@ struct rgk_scene {
     DevBuf<uint32_t> scratch_u;
     std::vector<hipEvent_t> events;
     uint32_t* h_counters = nullptr; // pinned
+    // progress, read by rgk_scene_get_progress from any thread
+    std::atomic<uint32_t> prog_stage{0}, prog_stages{0}, prog_rounds{0}, prog_busy{0};
+    std::atomic<uint64_t> prog_pixels{0}, prog_paths{0};
     ~rgk_scene() {
         (void)hipSetDevice(device);
         for (auto e : events) (void)hipEventDestroy(e);
@@ -882,6 +886,14 @@ int rgk_scene_get_info(const rgk_scene* s, rgk_scene_info* out) {
     return RGK_OK;
 }
 
+int rgk_scene_get_progress(const rgk_scene* s, rgk_progress* out) {
+    if (!s || !out) return fail(RGK_ERR_INVALID, "null argument");
+    out->stage = s->prog_stage.load(); out->stages = s->prog_stages.load(); out->rounds = s->prog_rounds.load(); out->busy = s->prog_busy.load();
+    out->round_pixels = s->prog_pixels.load(); out->round_paths = s->prog_paths.load();
+    if (out->stage > out->stages) out->stage = out->stages;
+    return RGK_OK;
+}
+
 int rgk_generate_task_list(uint32_t tile_size, uint32_t xres, uint32_t yres, float mid_x, float mid_y, uint32_t seedstart,
                            uint32_t seedcount_base, rgk_tile* tiles, uint32_t* n_tiles) {
     if (!n_tiles || tile_size == 0) return fail(RGK_ERR_INVALID, "bad argument");
@@ -1030,6 +1042,21 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
     } while (0)
 
     uint64_t path_rays = 0, shadow_rays = 0;
+    // progress: one stage per bounce per pass; a host function queued behind each bounce bumps the counter when the DEVICE gets there
+    {
+        const uint32_t n_pix_passes = (uint32_t)((P + npix_pass - 1) / npix_pass), n_s_passes = (prm->multisample + ns_pass - 1) / ns_pass;
+        s->prog_stage = 0; s->prog_stages = n_pix_passes * n_s_passes * std::max(1u, prm->depth);
+        s->prog_pixels = P; s->prog_paths = (uint64_t)P * prm->multisample; s->prog_busy = 1;
+    }
+    struct Done { rgk_scene* s; ~Done() { s->prog_stage = s->prog_stages.load(); s->prog_busy = 0; } } done_guard{s};
+    uint32_t stage_target = 0; // what prog_stage must read once everything queued so far has run
+    auto stage_mark = [&](uint32_t upto) -> int { // queued: "stages up to `upto` are done" (monotonic: bounces that never ran count too)
+        struct Msg { std::atomic<uint32_t>* c; uint32_t v; };
+        Msg* m = new Msg{&s->prog_stage, upto};
+        hipError_t e = hipLaunchHostFunc(st, [](void* p) { Msg* q = (Msg*)p; q->c->store(q->v); delete q; }, m);
+        if (e != hipSuccess) { delete m; return fail(RGK_ERR_DEVICE, "hipLaunchHostFunc: %s", hipGetErrorString(e)); }
+        return 0;
+    };
     PassParams pp{};
     pp.multisample = prm->multisample; pp.depth = prm->depth; pp.xres = prm->xres; pp.yres = prm->yres;
     pp.clamp = prm->clamp; pp.russian = prm->russian; pp.bumpmap_scale = prm->bumpmap_scale; pp.reverse = R;
@@ -1086,6 +1113,7 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
                                               s->rayA[q ^ 1].p, s->rayB[q ^ 1].p, s->shA.p, s->shB.p, s->shC.p, cn));
                     TIMED(1, rgk_launch_trace_shadow(st, s->dev, s->tcfg, count_stats, s->shA.p, s->shB.p, s->shC.p, s->tot.p, nullptr,
                                                      RGK_SHADOW_ADD, nullptr, cn + RGK_CNT_SHADOW + b, cn + RGK_CNT_FETCH_S + b, s->stats.p));
+                    if ((rc = stage_mark(stage_target + b + 1))) return rc;
                     if (track && b >= 3 && (b & 1) && b + 1 < prm->depth && (rc = queue_len(cn + RGK_CNT_QUEUE + b + 1, ub))) return rc;
                 }
             } else {
@@ -1115,10 +1143,13 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
                     TIMED(1, rgk_launch_trace_shadow(st, s->dev, s->tcfg, count_stats, s->shA.p, s->shB.p, s->shC.p, s->term.p, nullptr,
                                                      RGK_SHADOW_CELL, nullptr, cn + RGK_CNT_SHADOW + b, cn + RGK_CNT_FETCH_S + b, s->stats.p));
                     TIMED(3, rgk_launch_finish_vertex(st, pp, b, s->rayB[q].p, s->tot.p, cn));
+                    if ((rc = stage_mark(stage_target + b + 1))) return rc;
                     if (track && b >= 3 && (b & 1) && b + 1 < prm->depth && (rc = queue_len(cn + RGK_CNT_QUEUE + b + 1, ub))) return rc;
                 }
             }
             TIMED(3, rgk_launch_resolve(st, pp, s->tot.p, s->pixsum.p, d_accum_rgb, d_accum_count));
+            stage_target += std::max(1u, prm->depth);
+            if ((rc = stage_mark(stage_target))) return rc;
             HIPCHK(hipMemcpyAsync(s->h_counters, s->counters.p, 2 * RGK_CNT_TOTAL * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
             for (uint32_t b = 0; b < prm->depth; b++) { path_rays += s->h_counters[RGK_CNT_QUEUE + b]; shadow_rays += s->h_counters[RGK_CNT_SHADOW + b]; }
@@ -1126,6 +1157,7 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
         }
     }
     HIPCHK(hipGetLastError());
+    s->prog_rounds++;
     if (counters) {
         counters->paths = (uint64_t)P * prm->multisample;
         counters->path_rays = path_rays;

@@ -279,7 +279,7 @@ class RenderDriver:
             go = bool(flag.item())
         return go
 
-    def render_frame(self, rounds=None, minutes=None, output_file=None):
+    def render_frame(self, rounds=None, minutes=None, output_file=None, checkpoint=None):
         """RenderFrame: Rounds mode (render_driver.cpp:229-235) or Timed mode (:237-247); with `output_file` the
         normalised image is rewritten after every round, as the reference does (rank 0 only)."""
         rounds = self.cfg.render_rounds if rounds is None else rounds
@@ -290,6 +290,8 @@ class RenderDriver:
             self.render_round()
             if output_file and self.rank == 0:
                 self.total_ob.write(output_file, getattr(self.cfg, "output_scale", -1.0))
+            if checkpoint and self.rank == 0:
+                self.save_checkpoint(checkpoint)
         if minutes is None:
             for _ in range(rounds):
                 one()

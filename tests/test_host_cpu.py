@@ -31,14 +31,14 @@ def test_struct_layouts_match_the_header(tmp_path):
     """sizeof() of every struct, C compiler vs ctypes mirror."""
     src = tmp_path / "sz.c"
     names = ["rgk_material", "rgk_texture", "rgk_pointlight", "rgk_scene_desc", "rgk_camera", "rgk_params", "rgk_tile",
-             "rgk_counters", "rgk_scene_info", "rgk_hit"]
+             "rgk_counters", "rgk_scene_info", "rgk_hit", "rgk_progress"]
     src.write_text('#include <stdio.h>\n#include "rgk.h"\nint main(){' +
                    "".join(f'printf("%zu\\n", sizeof({n}));' for n in names) + "return 0;}")
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     mirrors = [capi.Material, capi.Texture, capi.PointLight, capi.SceneDesc, capi.Camera, capi.Params, capi.Tile,
-               capi.Counters, capi.SceneInfo, capi.Hit]
+               capi.Counters, capi.SceneInfo, capi.Hit, capi.Progress]
     assert sizes == [C.sizeof(m) for m in mirrors]
 
 
