@@ -132,7 +132,14 @@ typedef struct rgk_scene_desc {
      * tabM; m8==1, the rest 0).  Either may be NULL if no material uses it. */
     const float *ltc_ggx;
     const float *ltc_beckmann;
+
+    /* RGK_BUILD_*: how the accelerator is built (results never depend on it: hits come from the triangle records) */
+    uint32_t build_flags;
 } rgk_scene_desc;
+
+#define RGK_BUILD_HOST_SAH 0u /* binned-SAH on the host, collapsed to the 4-wide quantised BVH (default: best traversal)        */
+#define RGK_BUILD_DEVICE 1u   /* LBVH on the GPU (Morton sort, Karras hierarchy, refit, collapse + quantisation: all on the device):
+                                 milliseconds instead of a second at 1 M triangles, more node visits per ray                  */
 
 /* ---- Camera as RenderRound(const Camera&) receives it (src/render_driver.cpp:146): the public data members
  *      of the reference's Camera, src/camera.hpp:27-41, under their own names (`lookat` is not read on the path).

@@ -6,8 +6,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "librgk_hip.so")
-SOURCES = ["rgk_kernels.hip", "rgk_host.cpp", "rgk_output.cpp", "rgk_accum.cpp", "rgk_comm.cpp"]
-HEADERS = ["rgk_kernels.h", "rgk_device.h", "rgk_trace.h", "rgk_bdpt.h", "device_types.h", os.path.join("..", "..", "include", "rgk.h"), os.path.join("..", "..", "include", "rgk_libm.h")]
+SOURCES = ["rgk_kernels.hip", "rgk_build.hip", "rgk_host.cpp", "rgk_output.cpp", "rgk_accum.cpp", "rgk_comm.cpp"]
+HEADERS = ["rgk_kernels.h", "rgk_build.h", "rgk_device.h", "rgk_trace.h", "rgk_bdpt.h", "device_types.h", os.path.join("..", "..", "include", "rgk.h"), os.path.join("..", "..", "include", "rgk_libm.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          # CPU/GPU agreement: no FMA contraction on either side (DESIGN.md "Numerics")
          "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function", "-x", "hip"]

@@ -17,6 +17,7 @@ TEX_SOLID, TEX_RGB32F, TEX_RGB8 = 0, 1, 2
 SKY_COLOR, SKY_ENVMAP = 0, 1
 SAMPLER_HALTON, SAMPLER_STRATIFIED = 0, 1
 FLAG_COUNT_TRAVERSAL, FLAG_TIME_KERNELS = 1, 2
+BUILD_HOST_SAH, BUILD_DEVICE = 0, 1
 
 BRDF_IDS = {  # Material::LoadFromJson, reference src/bxdf/bxdf.cpp:63-84
     "diffusecosine": BXDF_DIFFUSE, "diffuse": BXDF_DIFFUSE, "mix": BXDF_MIX,
@@ -58,7 +59,7 @@ class SceneDesc(C.Structure):
                 ("areal_offsets", C.POINTER(C.c_uint32)), ("areal_tris", C.POINTER(C.c_uint32)),
                 ("sky_mode", C.c_uint32), ("sky_color", f3), ("sky_intensity", C.c_float),
                 ("sky_rotate", C.c_float), ("sky_texture", C.c_int32),
-                ("ltc_ggx", C.POINTER(C.c_float)), ("ltc_beckmann", C.POINTER(C.c_float))]
+                ("ltc_ggx", C.POINTER(C.c_float)), ("ltc_beckmann", C.POINTER(C.c_float)), ("build_flags", C.c_uint32)]
 
 
 class Camera(C.Structure):

@@ -25,6 +25,7 @@
 #include "../../include/rgk.h"
 #include "device_types.h"
 #include "rgk_kernels.h"
+#include "rgk_build.h"
 
 namespace {
 
@@ -328,6 +329,10 @@ struct DevBuf {
         hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
         if (e != hipSuccess) return fail(RGK_ERR_OOM, "hipMalloc(%zu bytes): %s", count * sizeof(T), hipGetErrorString(e));
         n = count;
+        // RGK_POISON=1: every fresh device buffer is filled with 0xFF bytes (NaN as float, huge as index), so that any read of
+        // memory the pipeline did not write first shows in the results instead of hiding behind zero-filled fresh pages
+        static const bool poison = std::getenv("RGK_POISON") != nullptr;
+        if (poison) (void)hipMemset(p, 0xFF, count * sizeof(T));
         return 0;
     }
     int upload(const std::vector<T>& v) {
@@ -669,11 +674,32 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
         }
     }
     // ---- accelerator
-    std::vector<BvhNode> nodes;
+    if (prims.empty()) return fail(RGK_ERR_INVALID, "every triangle is degenerate");
+    if (prims.size() >= (1u << 25)) return fail(RGK_ERR_UNSUPPORTED, "too many triangles (32-bit byte offsets into the triangle tables: < 2^25)");
+    std::vector<QNode> qnodes;
     std::vector<TriIsect> leaf_recs;
-    uint32_t max_depth = 0;
-    {
-        if (prims.empty()) return fail(RGK_ERR_INVALID, "every triangle is degenerate");
+    uint32_t max_depth = 0, max_stack = 0, n_nodes = 0, n_refs = (uint32_t)prims.size();
+    bool on_device = false;
+    const int MAX_LEAF_DEV = 4;
+    if ((d->build_flags & RGK_BUILD_DEVICE) && prims.size() > (size_t)MAX_LEAF_DEV) {
+        // LBVH on the GPU (rgk_build.hip): the references go up, nodes and leaf-ordered records stay on the device
+        std::vector<RgkBuildPrim> bp(prims.size());
+        for (size_t i = 0; i < prims.size(); i++) {
+            for (int a = 0; a < 3; a++) { bp[i].bmin[a] = prims[i].bmin[a]; bp[i].bmax[a] = prims[i].bmax[a]; }
+            bp[i].tri = prims[i].tri;
+        }
+        DevBuf<TriIsect> d_recs;
+        if ((rc = d_recs.upload(recs)) || (rc = s->nodes.alloc(prims.size())) || (rc = s->tris.alloc(prims.size()))) { d_recs.release(); return rc; }
+        uint32_t levels = 0;
+        const char* err = "";
+        rc = rgk_build_bvh4_device(s->stream, bp.data(), n_refs, mn, mx, eps, (uint32_t)MAX_LEAF_DEV, d_recs.p, s->nodes.p, s->tris.p, &n_nodes, &levels, &err);
+        d_recs.release();
+        if (rc) return fail(rc, "device BVH build: %s", err);
+        max_depth = levels;
+        max_stack = 3 * levels; // three pushes per level at most
+        on_device = true;
+    } else {
+        std::vector<BvhNode> nodes;
         BvhBuilder bb(prims, eps);
         Box rootbox;
         bb.nodes.reserve(prims.size());
@@ -693,17 +719,17 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
             if (code != 0) return fail(RGK_ERR_DEVICE, "internal: BVH root is not node 0");
         }
         nodes.swap(bb.nodes);
-        max_depth = bb.max_depth;
         leaf_recs.reserve(bb.order.size());
         for (uint32_t t : bb.order) leaf_recs.push_back(recs[t]);
-        if (bb.order.size() >= (1u << 25)) return fail(RGK_ERR_UNSUPPORTED, "too many triangles (32-bit byte offsets into the triangle tables: < 2^25)");
+        QbvhBuilder qb(nodes);
+        qb.out.reserve(nodes.size() / 2 + 1);
+        if (qb.collapse(0, 0, 0) != 0) return fail(RGK_ERR_DEVICE, "internal: QBVH root is not node 0");
+        qnodes.swap(qb.out);
+        max_depth = qb.max_depth; max_stack = qb.max_stack; n_nodes = (uint32_t)qnodes.size(); n_refs = (uint32_t)leaf_recs.size();
     }
-    QbvhBuilder qb(nodes);
-    qb.out.reserve(nodes.size() / 2 + 1);
-    if (qb.collapse(0, 0, 0) != 0) return fail(RGK_ERR_DEVICE, "internal: QBVH root is not node 0");
-    if (qb.max_stack + 1 > 256) return fail(RGK_ERR_UNSUPPORTED, "BVH needs %u traversal-stack entries (max 256)", qb.max_stack + 1);
+    if (max_stack + 1 > 256) return fail(RGK_ERR_UNSUPPORTED, "BVH needs %u traversal-stack entries (max 256)", max_stack + 1);
     {   // traversal stack: 16 entries per lane in LDS + per-lane overflow in global memory (rgk_kernels.hip RGK_TRACE_DISPATCH)
-        const int need = (int)qb.max_stack + 1;
+        const int need = (int)max_stack + 1;
         const char* e = std::getenv("RGK_STACK_OVF");
         const char* l = std::getenv("RGK_STACK_LDS");
         if (e && e[0] == '0' && need <= 32) { s->tcfg.stack = 32; s->tcfg.lds = 32; }
@@ -715,7 +741,6 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
             s->tcfg.ovf = s->ovf.p;
         }
     }
-    max_depth = qb.max_depth;
 
     // ---- shading arrays
     std::vector<TriShade> tsh(nt);
@@ -835,7 +860,8 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
     // ---- upload
     s->n_textures = d->n_textures; s->n_materials = d->n_materials;
     if ((rc = s->texrefs.upload(trefs))) return rc;
-    if ((rc = s->nodes.upload(qb.out)) || (rc = s->tris.upload(leaf_recs)) || (rc = s->tri_shade.upload(tsh)) ||
+    if (!on_device && ((rc = s->nodes.upload(qnodes)) || (rc = s->tris.upload(leaf_recs)))) return rc;
+    if ((rc = s->tri_shade.upload(tsh)) ||
         (rc = s->materials.upload(mats)) || (rc = s->texels.upload(pool)) || (rc = s->texels8.upload(pool8)) ||
         (rc = s->luts.upload(luts)) || (rc = s->pointlights.upload(pls)) || (rc = s->areal.upload(als)) ||
         (rc = s->areal_tris.upload(ats)) || (rc = s->hdims.upload(hd)) || (rc = s->hperm.upload(hp)))
@@ -852,7 +878,7 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
     }
     ds.nodes = s->nodes.p;
     { const char* e = std::getenv("RGK_WALK_Q"); ds.walk_q = e ? (uint32_t)std::atoi(e) : 3u; }
-    if (std::getenv("RGK_DEBUG_BVH")) std::fprintf(stderr, "[rgk] bvh4 nodes %zu max_stack %u max_depth %u refs %zu of %u triangles\n", qb.out.size(), qb.max_stack, qb.max_depth, leaf_recs.size(), nt);
+    if (std::getenv("RGK_DEBUG_BVH")) std::fprintf(stderr, "[rgk] bvh4 (%s) nodes %u max_stack %u max_depth %u refs %u of %u triangles\n", on_device ? "device LBVH" : "host SAH", n_nodes, max_stack, max_depth, n_refs, nt);
     ds.tris = s->tris.p; ds.tri_shade = s->tri_shade.p;
     ds.materials = s->materials.p; ds.texels = s->texels.p; ds.texels8 = s->texels8.p; ds.luts = s->luts.p; ds.n_lut_floats = (uint32_t)luts.size(); ds.n_materials = (uint32_t)mats.size();
     ds.pointlights = s->pointlights.p; ds.areal = s->areal.p; ds.areal_tris = s->areal_tris.p;
@@ -871,8 +897,8 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
     inf.epsilon = eps;
     for (int a = 0; a < 3; a++) { inf.bbox_min[a] = ds.bb_min[a]; inf.bbox_max[a] = ds.bb_max[a]; }
     inf.total_areal_power = total_areal; inf.total_point_power = total_point;
-    inf.n_nodes = (uint32_t)qb.out.size(); inf.node_bytes = RGK_NODE_BYTES; inf.tri_bytes = RGK_TRI_BYTES;
-    inf.max_depth = max_depth; inf.n_leaf_refs = (uint32_t)leaf_recs.size();
+    inf.n_nodes = n_nodes; inf.node_bytes = RGK_NODE_BYTES; inf.tri_bytes = RGK_TRI_BYTES;
+    inf.max_depth = max_depth; inf.n_leaf_refs = n_refs;
     guard.s = nullptr;
     *out = s;
     return RGK_OK;

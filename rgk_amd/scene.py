@@ -535,7 +535,7 @@ class SceneBuilder:
         return any(m["kind"] >= capi.BXDF_LTC_BECKMANN for m in self.materials)
 
     def to_desc(self):
-        """Build the rgk_scene_desc (keeps every buffer alive on self)."""
+        """Build the rgk_scene_desc (every buffer is kept alive on self and on the returned descriptor)."""
         self.finalize()
         keep = self._keep = []
         fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
@@ -586,5 +586,7 @@ class SceneBuilder:
         bek = np.fromfile(os.path.join(HERE, "data", "ltc_beckmann.f32"), dtype=f32)
         assert ggx.size == 5 * 4096 and bek.size == 5 * 4096
         d.ltc_ggx, d.ltc_beckmann = fp(ggx), fp(bek)
+        d.build_flags = capi.BUILD_DEVICE if os.environ.get("RGK_BVH_BUILD", "").lower() in ("gpu", "device") else getattr(self, "build_flags", capi.BUILD_HOST_SAH)
         keep += [mats, texs, pls, offs, tris, ggx, bek]
+        d._keep = keep  # the descriptor owns its buffers too: `builder.to_desc()` on a temporary builder stays valid
         return d

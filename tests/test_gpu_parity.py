@@ -770,3 +770,51 @@ def test_pinned_libm_same_bits_on_gpu_and_cpu(oracle, product_lib):
         both_nan = np.isnan(cpu) & np.isnan(gpu)
         record_parity(f"test_pinned_libm_same_bits_on_gpu_and_cpu:fn{fn}", n=len(a), bit_identical=float((same | both_nan).mean()))
         assert (same | both_nan).all(), (fn, a[~(same | both_nan)][:5], cpu[~(same | both_nan)][:5], gpu[~(same | both_nan)][:5])
+
+
+# ----------------------------------------------------------------------- f2: the accelerator built on the device
+def test_device_built_bvh_gives_the_same_hits(rd, oracle):
+    """the LBVH built on the GPU (Morton sort, Karras hierarchy, refit, collapse + quantisation on the device,
+    rgk_build.hip) against the host's binned-SAH tree: another tree over the same triangle records, so every hit must be the
+    same (t, triangle, barycentrics bit for bit; different triangle only inside the epsilon tie band) -- on cube3, box6, the
+    Sponza proxy and the 1.05 M-triangle dragon scene; images equal too.  Records build time and node visits per ray of both."""
+    import time
+    from rgk_amd.workloads import Workload
+    cases = [("cube3", scene_fixture("cube3", scale=0.1, spp=4)), ("box6", scene_fixture("box6", scale=0.1, spp=4)),
+             ("sponza-proxy", Workload("sponza-1080p", scale=0.1, spp=4)), ("dragon-sponza-proxy 1.05 M", Workload("dragon-sponza-1080p", scale=0.05, spp=2))]
+    for name, wl in cases:
+        sb = wl.builder
+        sb.build_flags = capi.BUILD_HOST_SAH
+        t0 = time.time(); gh = rd.Scene(sb.to_desc()); th = time.time() - t0
+        sb.build_flags = capi.BUILD_DEVICE
+        t0 = time.time(); gd = rd.Scene(sb.to_desc()); td = time.time() - t0
+        sb.build_flags = capi.BUILD_HOST_SAH
+        ih, idv = gh.info(), gd.info()
+        assert ih.epsilon == idv.epsilon and list(ih.bbox_min) == list(idv.bbox_min) and idv.n_leaf_refs == ih.n_leaf_refs
+        lo, hi = np.array(list(ih.bbox_min)), np.array(list(ih.bbox_max))
+        oo, dd = random_rays(np.random.default_rng(41), lo, hi, 200000)
+        rays = make_rays(oo, dd)
+        hh, ch = gh.trace_closest(rays, count=True)
+        hd, cd = gd.trace_closest(rays, count=True)
+        same = hh["tri"] == hd["tri"]
+        for k in ("t", "a", "b", "c"):
+            assert np.array_equal(hh[k][same].view(np.uint32), hd[k][same].view(np.uint32)), (name, k)
+        bad = ~same
+        with np.errstate(invalid="ignore"):
+            tie = bad & (hh["tri"] >= 0) & (hd["tri"] >= 0) & (np.abs(hh["t"] - hd["t"]) <= 2 * ih.epsilon)
+        record_parity("test_device_built_bvh_gives_the_same_hits:" + name, triangles=len(sb.F), same_triangle=float(same.mean()), eps_band_ties=int(tie.sum()),
+                      unexplained=int(bad.sum() - tie.sum()), host_scene_s=th, device_scene_s=td, host_nodes=ih.n_nodes, device_nodes=idv.n_nodes,
+                      host_nodes_per_ray=ch.node_visits / len(rays), device_nodes_per_ray=cd.node_visits / len(rays),
+                      host_trace_ms=ch.ms_trace, device_trace_ms=cd.ms_trace, device_levels=idv.max_depth)
+        assert bad.sum() - tie.sum() <= max(1, 5e-5 * len(rays)), (name, int(bad.sum()), int(tie.sum()))
+        a = (lo + (hi - lo) * np.random.default_rng(42).uniform(0.02, 0.98, (100000, 3))).astype(np.float32)
+        b = (lo + (hi - lo) * np.random.default_rng(43).uniform(0.02, 0.98, (100000, 3))).astype(np.float32)
+        assert (gh.visibility(a, b)[0] == gd.visibility(a, b)[0]).mean() > 0.9999
+        prm = wl.params()
+        tiles = rd.generate_task_list(wl.xres, wl.yres)
+        ah = gh.render_round(wl.camera, prm, tiles)[0]
+        ad = gd.render_round(wl.camera, prm, tiles)[0]
+        rel = float(np.linalg.norm(ah - ad) / np.linalg.norm(ah))
+        record_parity("test_device_built_bvh_gives_the_same_hits:" + name + ":image", rel_l2=rel, bit_identical=float((np.abs(ah - ad).max(axis=2) == 0).mean()))
+        assert rel <= 5e-3
+        gh.close(); gd.close()
