@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void k_raygen_light(const DevScene sc, const D
     const uint32_t n = pp.npix * pp.ns;
     const SamplerTab tb = {pp.htab, pp.multisample};
     for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n; slot += gridDim.x * blockDim.x) {
-        const uint32_t srel = slot / pp.npix, j = slot - srel * pp.npix;
+        uint32_t srel, j; slot_decode(pp, slot, j, srel);
         const uint32_t seed = pp.pix_seed[pp.j0 + j], s = pp.s0 + srel;
         const uint32_t base2d = (cam.lens_size != 0.0f) ? 2u : 1u;
         const float2 areal_s = sample2d_t(tb, seed, s, base2d), lightdir_s = sample2d_t(tb, seed, s, base2d + 1u);
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void k_raygen_camera(const DevScene sc, const 
     const uint32_t n = pp.npix * pp.ns;
     const SamplerTab tb = {pp.htab, pp.multisample};
     for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n; slot += gridDim.x * blockDim.x) {
-        const uint32_t srel = slot / pp.npix, j = slot - srel * pp.npix;
+        uint32_t srel, j; slot_decode(pp, slot, j, srel);
         const uint32_t pix = pp.pix_xy[pp.j0 + j], seed = pp.pix_seed[pp.j0 + j], s = pp.s0 + srel;
         const float2 jit = sample2d_t(tb, seed, s, 0);
         float2 lens = make_float2(0.f, 0.f);
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade_light(const DevSce
                 surface_point(sc, pp.bumpmap_scale, o, d, h, v);
                 defer = !GENERIC && v.ok && !mat_is_fast(v.mat.kind);
                 if (v.ok && !defer) {
-                    const uint32_t srel = slot / pp.npix, j = slot - srel * pp.npix;
+                    uint32_t srel, j; slot_decode(pp, slot, j, srel);
                     const uint32_t seed = pp.pix_seed[pp.j0 + j], s = pp.s0 + srel;
                     const uint32_t base2d = (cam.lens_size != 0.0f) ? 2u : 1u;
                     MatPrep mp;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade_bdpt(const DevScen
                 }
                 if (v.ok && !defer) {
                     have = true;
-                    const uint32_t srel = slot / pp.npix, j = slot - srel * pp.npix;
+                    uint32_t srel, j; slot_decode(pp, slot, j, srel);
                     const uint32_t seed = pp.pix_seed[pp.j0 + j], s = pp.s0 + srel;
                     const uint32_t base2d = (cam.lens_size != 0.0f) ? 2u : 1u;
                     mat_prepare(sc, v.mat, v.uv, v.VrL, n < pp.depth, mp);

@@ -594,6 +594,9 @@ static void debug_desc(const rgk_scene_desc* d) {
                  d->sky_intensity, d->sky_rotate, d->sky_texture, h(d->ltc_ggx, 4096 * 20), h(d->ltc_beckmann, 4096 * 20));
 }
 
+#ifndef RGK_SAMPLE_GROUP_DEFAULT
+#define RGK_SAMPLE_GROUP_DEFAULT 3 // 8 samples of a pixel side by side: swept 0..6 on the Sponza proxy (154.2, -, 149.6, 148.4, 148.1, 150.3, 150.0 ms per round)
+#endif
 int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
     if (!out) return fail(RGK_ERR_INVALID, "null output pointer");
     *out = nullptr;
@@ -1121,6 +1124,12 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
         for (uint32_t s0 = 0; s0 < prm->multisample; s0 += ns_pass) {
             pp.s0 = s0;
             pp.ns = std::min(ns_pass, prm->multisample - s0);
+            {   // 2^gshift samples of a pixel side by side in the slot order (rgk_kernels.h PassParams); RGK_SAMPLE_GROUP = log2
+                static const uint32_t want = [] { const char* e = std::getenv("RGK_SAMPLE_GROUP"); return e ? (uint32_t)std::min(6, std::max(0, std::atoi(e))) : (uint32_t)RGK_SAMPLE_GROUP_DEFAULT; }();
+                uint32_t g = want;
+                while (g && (pp.ns & ((1u << g) - 1u))) g--;
+                pp.gshift = g;
+            }
             const uint32_t n0 = pp.npix * pp.ns;
             uint32_t* cn = s->counters.p;                   // camera-phase counters
             uint32_t* cl = s->counters.p + RGK_CNT_TOTAL;   // light-phase counters
@@ -1269,6 +1278,9 @@ int rgk_trace_closest(rgk_scene* s, uint32_t n, const float* rays, const int32_t
         unsigned long long h[8];
         HIPCHK(hipMemcpy(h, s->stats.p, sizeof(h), hipMemcpyDeviceToHost));
         counters->node_visits = h[0]; counters->tri_tests = h[1]; counters->path_rays = n;
+        if (std::getenv("RGK_DEBUG_UTIL")) // lane occupancy per phase of the walker: lane-visits / (64 x wave iterations)
+            std::fprintf(stderr, "[rgk util] rays %u  node visits %llu in %llu wave iterations (%.3f of lanes)  triangle tests %llu in %llu (%.3f)  outer iterations %llu  refills %llu\n",
+                         n, h[0], h[4], h[4] ? (double)h[0] / (64.0 * (double)h[4]) : 0.0, h[1], h[5], h[5] ? (double)h[1] / (64.0 * (double)h[5]) : 0.0, h[6], h[7]);
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, e0, e1));
         counters->ms_trace = ms; counters->n_trace_launches = 1;

@@ -29,9 +29,13 @@
 #define RGK_SHADOW_SPLAT 2 // atomicAdd(accum_rgb[pixel], radiance)     (BDPT: light-tracing side effect)
 
 // One pass = pixels [j0, j0+npix) of the round's pixel list x samples [s0, s0+ns).
-// Path slot = (s - s0) * npix + (j - j0).
+// Path slot = ((srel >> g) * npix + j) << g | (srel & (2^g - 1)) with srel = s - s0, j = pixel - j0, g = gshift: 2^g consecutive
+// samples of a pixel sit side by side, so a wave of 64 slots is 64 >> g neighbouring pixels x 2^g samples -- rays that differ by
+// sub-pixel jitter walk the same nodes and shade the same triangle and texels (g = 0: one sample of 64 pixels, round 1's
+// order).  ns is a multiple of 2^g (the host falls back to g = 0 otherwise).
 struct PassParams {
     uint32_t j0, npix, s0, ns;
+    uint32_t gshift;
     uint32_t multisample, depth, xres, yres;
     float clamp, russian, bumpmap_scale;
     uint32_t reverse;
@@ -48,6 +52,16 @@ struct PassParams {
     uint32_t batch;
     uint32_t* generic;        // queue indices of the vertices whose material takes the generic BxDF route (k_shade)
 };
+
+// slot <-> (pixel of the pass, sample of the pass)
+__device__ __forceinline__ void slot_decode(const PassParams& pp, uint32_t slot, uint32_t& j, uint32_t& srel) {
+    const uint32_t r = slot >> pp.gshift, sb = r / pp.npix;
+    j = r - sb * pp.npix;
+    srel = (sb << pp.gshift) | (slot & ((1u << pp.gshift) - 1u));
+}
+__device__ __forceinline__ uint32_t slot_of(const PassParams& pp, uint32_t j, uint32_t srel) {
+    return ((((srel >> pp.gshift) * pp.npix) + j) << pp.gshift) | (srel & ((1u << pp.gshift) - 1u));
+}
 
 void rgk_launch_init_counters(hipStream_t st, uint32_t* counters, uint32_t n0);
 void rgk_launch_build_pixel_list(hipStream_t st, const rgk_tile* tiles, const uint32_t* tile_off, uint32_t n_tiles, uint32_t* pix_xy, uint32_t* pix_seed);

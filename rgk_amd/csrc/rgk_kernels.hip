@@ -70,7 +70,7 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, RGK_SHADE_WAVES) void k_shade(cons
             uint32_t n = (bits & 0xffffu) + 1u; // n++ at loop top, reference path_tracer.cpp:123
             uint32_t c1 = bits >> 16;
             const int tri = __float_as_int(h.w);
-            const uint32_t srel = slot / pp.npix, j = slot - srel * pp.npix;
+            uint32_t srel, j; slot_decode(pp, slot, j, srel);
             const uint32_t seed = pp.pix_seed[pp.j0 + j];
             const uint32_t s = pp.s0 + srel;
             const uint32_t base2d = (cam.lens_size != 0.0f) ? 2u : 1u;
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void k_resolve(const PassParams pp, const floa
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < pp.npix; j += gridDim.x * blockDim.x) {
         float4 acc = (pp.s0 == 0) ? make_float4(0.f, 0.f, 0.f, 0.f) : pixsum[pp.j0 + j];
         for (uint32_t srel = 0; srel < pp.ns; srel++) {
-            float4 t = tot[srel * pp.npix + j];
+            float4 t = tot[slot_of(pp, j, srel)];
             f3 v = clamp3(mk3(t.x, t.y, t.z), pp.clamp);
             if (v.x != v.x || v.x < 0.0f) v.x = 0.0f;
             if (v.y != v.y || v.y < 0.0f) v.y = 0.0f;
@@ -280,6 +280,50 @@ __global__ __launch_bounds__(256) void k_resolve(const PassParams pp, const floa
             accum_count[p] += pp.multisample;
         } else {
             pixsum[pp.j0 + j] = acc;
+        }
+    }
+}
+
+// The same for gshift > 0, where the 2^g samples of a pixel are contiguous (a thread walking its pixel's samples would stride
+// 2^g * 16 bytes against its neighbours): one wave per PT pixels stages each sample block through LDS with coalesced loads, then
+// lane p sums pixel p's samples in sample order -- the same additions in the same order as above.
+__global__ __launch_bounds__(64) void k_resolve_tiled(const PassParams pp, const float4* __restrict__ tot, float4* __restrict__ pixsum,
+                                                       float* __restrict__ accum_rgb, uint32_t* __restrict__ accum_count, const uint32_t PT) {
+    extern __shared__ float4 tile[]; // [PT pixels][G + 1], PT <= 64
+    const uint32_t G = 1u << pp.gshift, lane = threadIdx.x;
+    for (uint32_t jb = blockIdx.x * PT; jb < pp.npix; jb += gridDim.x * PT) {
+        const uint32_t np = min(PT, pp.npix - jb), j = jb + lane;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < np && pp.s0 != 0) acc = pixsum[pp.j0 + j];
+        for (uint32_t sb = 0; sb < (pp.ns >> pp.gshift); sb++) {
+            const float4* __restrict__ src = tot + ((size_t)(sb * pp.npix + jb) << pp.gshift); // np * G consecutive slots
+            for (uint32_t k = 0; k * 64u < np * G; k++) {
+                const uint32_t idx = k * 64u + lane;
+                if (idx < np * G) tile[(idx >> pp.gshift) * (G + 1u) + (idx & (G - 1u))] = src[idx];
+            }
+            __syncthreads();
+            if (lane < np)
+                for (uint32_t g = 0; g < G; g++) {
+                    const float4 t = tile[lane * (G + 1u) + g];
+                    f3 v = clamp3(mk3(t.x, t.y, t.z), pp.clamp);
+                    if (v.x != v.x || v.x < 0.0f) v.x = 0.0f;
+                    if (v.y != v.y || v.y < 0.0f) v.y = 0.0f;
+                    if (v.z != v.z || v.z < 0.0f) v.z = 0.0f;
+                    acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z;
+                }
+            __syncthreads();
+        }
+        if (lane < np) {
+            if (pp.s0 + pp.ns >= pp.multisample) {
+                uint32_t pix = pp.pix_xy[pp.j0 + j];
+                size_t p = (size_t)(pix >> 16) * pp.xres + (pix & 0xffff);
+                accum_rgb[3 * p + 0] += acc.x;
+                accum_rgb[3 * p + 1] += acc.y;
+                accum_rgb[3 * p + 2] += acc.z;
+                accum_count[p] += pp.multisample;
+            } else {
+                pixsum[pp.j0 + j] = acc;
+            }
         }
     }
 }
@@ -305,7 +349,7 @@ __global__ __launch_bounds__(256) void k_build_pixel_list(const rgk_tile* __rest
             if (c > nbc - 1u) c = nbc - 1u;
             const uint32_t rem2 = rem - c * bh * 8u;
             const uint32_t bw = (tw - 8u * c) < 8u ? (tw - 8u * c) : 8u;
-            const uint32_t y = 8u * r + rem2 / bw, x = 8u * c + rem2 % bw;
+            const uint32_t y = 8u * r + rem2 / bw, x = 8u * c + rem2 % bw; // (Z order inside the block: no difference measured)
             const uint32_t k = y * tw + x;
             pix_xy[base + q] = (tl.x0 + x) | ((tl.y0 + y) << 16);
             pix_seed[base + q] = tl.seed + (k + 1u) * 0x42424242u;
@@ -517,7 +561,11 @@ void rgk_launch_shade(hipStream_t st, const DevScene& sc, const DevCamera& cam, 
 void rgk_launch_resolve(hipStream_t st, const PassParams& pp, const float4* tot, float4* pixsum, float* accum_rgb, uint32_t* accum_count) {
     int grid = (int)((pp.npix + 255) / 256);
     if (grid > 256 * 16) grid = 256 * 16;
-    k_resolve<<<grid, 256, 0, st>>>(pp, tot, pixsum, accum_rgb, accum_count);
+    if (pp.gshift == 0) { k_resolve<<<grid, 256, 0, st>>>(pp, tot, pixsum, accum_rgb, accum_count); return; }
+    const uint32_t G = 1u << pp.gshift;
+    const uint32_t PT = G <= 32 ? 64u : 2048u / G; // pixels per tile: at most ~33 KB of LDS per wave
+    int tiles = (int)((pp.npix + PT - 1) / PT);
+    k_resolve_tiled<<<tiles > 256 * 64 ? 256 * 64 : tiles, 64, PT * (G + 1) * sizeof(float4), st>>>(pp, tot, pixsum, accum_rgb, accum_count, PT);
 }
 
 void rgk_launch_pack_rays(hipStream_t st, uint32_t n, const float* rays, const int32_t* ignore, float4* rayA, float4* rayB, float2* nearfar) {

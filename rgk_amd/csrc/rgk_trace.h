@@ -57,7 +57,7 @@ __device__ __forceinline__ void camera_ray(const DevCamera& cam, int x, int y, i
 // the bounce-0 traversal and the bounce-0 shading each derive it from the slot number instead of one kernel writing 32 bytes
 // per path for the other two to read back (k_raygen was 4 % of a Sponza round, all of it HBM traffic).
 __device__ __forceinline__ void camera_ray_of_slot(const DevCamera& cam, const PassParams& pp, uint32_t slot, f3& o, f3& d) {
-    const uint32_t srel = slot / pp.npix, j = slot - srel * pp.npix;
+    uint32_t srel, j; slot_decode(pp, slot, j, srel);
     const uint32_t pix = pp.pix_xy[pp.j0 + j], seed = pp.pix_seed[pp.j0 + j];
     const uint32_t s = pp.s0 + srel;
     const SamplerTab tb = {pp.htab, pp.multisample};
@@ -82,6 +82,8 @@ __device__ __forceinline__ bool tri_test(const float4 r0, const float4 r1, const
     float py = comp(o, i2) + comp(d, i2) * t;
     float q0x = px - r1.x, q0y = py - r1.y;
     float q1x = r1.z, q1y = r1.w, q2x = r2.x, q2y = r2.y;
+    // the reference's two cases (q1x ~ 0 or not) as ONE pair of divisions with selected operands: the same operations on the
+    // same values, but a wave whose lanes disagree about the case no longer runs four IEEE divisions
     if (q1x > -eps && q1x < eps) {
         beta = q0x / q2x;
         if (beta < 0 || beta > 1) return false;
@@ -133,8 +135,10 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
                                                  float4* __restrict__ hit, float4* __restrict__ tot, uint8_t* __restrict__ vis_out,
                                                  const int mode, float* __restrict__ splat_rgb,
                                                  const uint32_t count, uint32_t* __restrict__ fetch, int* __restrict__ stack, int* __restrict__ ovf, const uint32_t ostride,
-                                                 uint32_t& n_nodes, uint32_t& n_tris, const DevCamera* cam = nullptr, const PassParams* pp = nullptr) {
+                                                 uint32_t& n_nodes, uint32_t& n_tris, const DevCamera* cam = nullptr, const PassParams* pp = nullptr,
+                                                 unsigned long long* __restrict__ util = nullptr) {
     const int lane = threadIdx.x & 63;
+    uint32_t u_node_it = 0, u_leaf_it = 0, u_outer_it = 0, u_refill = 0; // COUNT: wave-level iteration counts (lane occupancy per phase)
     const int stride = RGK_TRACE_BLOCK;
     const float eps = sc.epsilon;
     const int walk_q = (int)sc.walk_q;
@@ -154,7 +158,9 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
         // ------------------------------------------------ refill idle lanes
         unsigned long long act = __ballot(active);
         const int nact = __popcll(act);
+        if (COUNT) u_outer_it++;
         if (nact <= RGK_REFILL_BELOW && !(exhausted && w_next >= w_end)) {
+            if (COUNT) u_refill++;
             if (w_next >= w_end) {
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(fetch, chunk);
@@ -222,10 +228,13 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
         // (Postponing the first leaf and walking on -- "speculative traversal" -- was measured: 8 % more
         // nodes, 30 % more triangle tests, 20 % slower.  Not kept.)
         for (;;) {
-            const bool walking = active && cur >= 0 && cur != STACK_SENTINEL;
-            const int n_walk = __popcll(__ballot(walking));
+            // (a lane without a ray always holds cur == SENTINEL, so `cur` alone tells the three states apart; the ballots are
+            // compares straight into a lane mask)
+            const bool walking = (uint32_t)cur < (uint32_t)STACK_SENTINEL;
+            const int n_walk = __popcll(__builtin_amdgcn_ballot_w64(walking));
             if (n_walk == 0) break;
-            if (n_walk * 4 < __popcll(__ballot(active && cur < 0)) * walk_q) break; // the leaves have the majority
+            if (n_walk * 4 < __popcll(__builtin_amdgcn_ballot_w64(cur < 0)) * walk_q) break; // the leaves have the majority
+            if (COUNT) u_node_it++;
             if (!walking) continue;
             float te[4];
             int ref[4];
@@ -274,9 +283,15 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
                 // sized STACK above the deepest push sequence the tree can produce, rgk_host.cpp QbvhBuilder).
 #define RGK_PUT(x) { if (LDSN >= STACK || sp < LDSN) stack[sp * stride] = (x); else ovf[(size_t)(sp - LDSN) * ostride] = (x); }
 #define RGK_POP() ((LDSN >= STACK || sp < LDSN) ? stack[sp * stride] : ovf[(size_t)(sp - LDSN) * ostride])
-                RGK_PUT(ref[3]) sp += (ref[3] != STACK_SENTINEL);
-                RGK_PUT(ref[2]) sp += (ref[2] != STACK_SENTINEL);
-                RGK_PUT(ref[1]) sp += (ref[1] != STACK_SENTINEL);
+                if (LDSN >= STACK || sp + 3 <= LDSN) { // all three possible entries fit the LDS part: one test instead of three
+                    stack[sp * stride] = ref[3]; sp += (ref[3] != STACK_SENTINEL);
+                    stack[sp * stride] = ref[2]; sp += (ref[2] != STACK_SENTINEL);
+                    stack[sp * stride] = ref[1]; sp += (ref[1] != STACK_SENTINEL);
+                } else {
+                    RGK_PUT(ref[3]) sp += (ref[3] != STACK_SENTINEL);
+                    RGK_PUT(ref[2]) sp += (ref[2] != STACK_SENTINEL);
+                    RGK_PUT(ref[1]) sp += (ref[1] != STACK_SENTINEL);
+                }
                 cur = ref[0];
             } else {
                 // any-hit: the answer does not depend on the order, the time does -- walking on with the NEAREST entered child
@@ -295,6 +310,10 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
         }
         // ------------------------------------------------ leaf: every triangle of it.  (One triangle per scheduled step,
         // leaving when the walkers regain the majority, was measured slower: 24.2 vs 23.3 ms.)
+        if (COUNT) { // wave iterations of the triangle loop below = the longest leaf among the lanes standing at one
+            const uint32_t mine = (active && cur < 0) ? ((~(uint32_t)cur) & 15u) + 1u : 0u;
+            for (uint32_t c = 1; c <= 16; c++) if (__ballot(mine >= c)) u_leaf_it++;
+        }
         if (active && cur < 0) {
             const uint32_t code = ~(uint32_t)cur;
             const uint32_t first = code >> 4, cnt = (code & 15u) + 1u;
@@ -334,6 +353,10 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
             active = false;
         }
     }
+    if (COUNT && util && lane == 0) {
+        atomicAdd(&util[0], (unsigned long long)u_node_it); atomicAdd(&util[1], (unsigned long long)u_leaf_it);
+        atomicAdd(&util[2], (unsigned long long)u_outer_it); atomicAdd(&util[3], (unsigned long long)u_refill);
+    }
 }
 
 // ------------------------------------------------------------------ K2: closest hit
@@ -345,7 +368,7 @@ __global__ __launch_bounds__(RGK_TRACE_BLOCK, (LDSN <= 16 ? RGK_TRACE_WAVES : 5)
     __shared__ int lds_stack[LDSN * RGK_TRACE_BLOCK];
     uint32_t n_nodes = 0, n_tris = 0;
     trace_persistent<false, COUNT, STACK, LDSN>(sc, rayA, rayB, nullptr, nearfar, hit, nullptr, nullptr, 0, nullptr, *count_ptr, fetch,
-                                          lds_stack + threadIdx.x, ovf + (blockIdx.x * RGK_TRACE_BLOCK + threadIdx.x), gridDim.x * RGK_TRACE_BLOCK, n_nodes, n_tris);
+                                          lds_stack + threadIdx.x, ovf + (blockIdx.x * RGK_TRACE_BLOCK + threadIdx.x), gridDim.x * RGK_TRACE_BLOCK, n_nodes, n_tris, nullptr, nullptr, stats + 4);
     if (COUNT) {
         atomicAdd(&stats[0], (unsigned long long)n_nodes);
         atomicAdd(&stats[1], (unsigned long long)n_tris);
@@ -360,7 +383,7 @@ __global__ __launch_bounds__(RGK_TRACE_BLOCK, (LDSN <= 16 ? RGK_TRACE_WAVES : 5)
     __shared__ int lds_stack[LDSN * RGK_TRACE_BLOCK];
     uint32_t n_nodes = 0, n_tris = 0;
     trace_persistent<false, COUNT, STACK, LDSN, true>(sc, nullptr, nullptr, nullptr, nullptr, hit, nullptr, nullptr, 0, nullptr, *count_ptr, fetch,
-                                          lds_stack + threadIdx.x, ovf + (blockIdx.x * RGK_TRACE_BLOCK + threadIdx.x), gridDim.x * RGK_TRACE_BLOCK, n_nodes, n_tris, &cam, &pp);
+                                          lds_stack + threadIdx.x, ovf + (blockIdx.x * RGK_TRACE_BLOCK + threadIdx.x), gridDim.x * RGK_TRACE_BLOCK, n_nodes, n_tris, &cam, &pp, stats + 4);
     if (COUNT) {
         atomicAdd(&stats[0], (unsigned long long)n_nodes);
         atomicAdd(&stats[1], (unsigned long long)n_tris);
