@@ -390,12 +390,14 @@ struct rgk_scene {
     std::vector<hipEvent_t> events;
     uint32_t* h_counters = nullptr; // pinned
     // progress, read by rgk_scene_get_progress from any thread
-    std::atomic<uint32_t> prog_stage{0}, prog_stages{0}, prog_rounds{0}, prog_busy{0};
+    std::atomic<uint32_t> prog_stages{0}, prog_rounds{0}, prog_busy{0};
+    uint32_t* h_stage = nullptr; // pinned word the DEVICE writes (k_stage_mark): stages of the running round that are done
     std::atomic<uint64_t> prog_pixels{0}, prog_paths{0};
     ~rgk_scene() {
         (void)hipSetDevice(device);
         for (auto e : events) (void)hipEventDestroy(e);
         if (h_counters) (void)hipHostFree(h_counters);
+        if (h_stage) (void)hipHostFree(h_stage);
         nodes.release(); tris.release(); tri_shade.release(); materials.release(); texels8.release(); luts.release();
         texels.release(); pointlights.release(); areal.release(); areal_tris.release(); ltc.release(); self.release(); ovf.release();
         hdims.release(); hperm.release(); texrefs.release();
@@ -434,6 +436,7 @@ int ensure_workspace(rgk_scene* s, size_t paths, uint32_t reverse = 0) {
     if (!rc) rc = s->stats.alloc(8);
     if (rc) { s->batch = 0; s->batch_reverse = 0; return rc; } // some buffers are gone: the next call starts over
     if (!s->h_counters) HIPCHK(hipHostMalloc((void**)&s->h_counters, 2 * RGK_CNT_TOTAL * sizeof(uint32_t)));
+    if (!s->h_stage) { HIPCHK(hipHostMalloc((void**)&s->h_stage, sizeof(uint32_t))); *s->h_stage = 0; }
     s->batch = paths;
     s->batch_reverse = reverse;
     return 0;
@@ -917,7 +920,7 @@ int rgk_scene_get_info(const rgk_scene* s, rgk_scene_info* out) {
 
 int rgk_scene_get_progress(const rgk_scene* s, rgk_progress* out) {
     if (!s || !out) return fail(RGK_ERR_INVALID, "null argument");
-    out->stage = s->prog_stage.load(); out->stages = s->prog_stages.load(); out->rounds = s->prog_rounds.load(); out->busy = s->prog_busy.load();
+    out->stage = s->h_stage ? *(volatile const uint32_t*)s->h_stage : 0u; out->stages = s->prog_stages.load(); out->rounds = s->prog_rounds.load(); out->busy = s->prog_busy.load();
     out->round_pixels = s->prog_pixels.load(); out->round_paths = s->prog_paths.load();
     if (out->stage > out->stages) out->stage = out->stages;
     return RGK_OK;
@@ -1071,19 +1074,18 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
     } while (0)
 
     uint64_t path_rays = 0, shadow_rays = 0;
-    // progress: one stage per bounce per pass; a host function queued behind each bounce bumps the counter when the DEVICE gets there
+    // progress: one stage per bounce per pass; a one-thread kernel queued behind each bounce writes the stage number into pinned
+    // host memory when the DEVICE gets there (a host function in the stream did the same but stalls the stream for a host
+    // round trip per mark)
     {
         const uint32_t n_pix_passes = (uint32_t)((P + npix_pass - 1) / npix_pass), n_s_passes = (prm->multisample + ns_pass - 1) / ns_pass;
-        s->prog_stage = 0; s->prog_stages = n_pix_passes * n_s_passes * std::max(1u, prm->depth);
+        *(volatile uint32_t*)s->h_stage = 0; s->prog_stages = n_pix_passes * n_s_passes * std::max(1u, prm->depth);
         s->prog_pixels = P; s->prog_paths = (uint64_t)P * prm->multisample; s->prog_busy = 1;
     }
-    struct Done { rgk_scene* s; ~Done() { s->prog_stage = s->prog_stages.load(); s->prog_busy = 0; } } done_guard{s};
-    uint32_t stage_target = 0; // what prog_stage must read once everything queued so far has run
+    struct Done { rgk_scene* s; ~Done() { *(volatile uint32_t*)s->h_stage = s->prog_stages.load(); s->prog_busy = 0; } } done_guard{s};
+    uint32_t stage_target = 0; // what the stage word must read once everything queued so far has run
     auto stage_mark = [&](uint32_t upto) -> int { // queued: "stages up to `upto` are done" (monotonic: bounces that never ran count too)
-        struct Msg { std::atomic<uint32_t>* c; uint32_t v; };
-        Msg* m = new Msg{&s->prog_stage, upto};
-        hipError_t e = hipLaunchHostFunc(st, [](void* p) { Msg* q = (Msg*)p; q->c->store(q->v); delete q; }, m);
-        if (e != hipSuccess) { delete m; return fail(RGK_ERR_DEVICE, "hipLaunchHostFunc: %s", hipGetErrorString(e)); }
+        rgk_launch_stage_mark(st, s->h_stage, upto);
         return 0;
     };
     PassParams pp{};
@@ -1125,8 +1127,8 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
             pp.s0 = s0;
             pp.ns = std::min(ns_pass, prm->multisample - s0);
             {   // 2^gshift samples of a pixel side by side in the slot order (rgk_kernels.h PassParams); RGK_SAMPLE_GROUP = log2
-                static const uint32_t want = [] { const char* e = std::getenv("RGK_SAMPLE_GROUP"); return e ? (uint32_t)std::min(6, std::max(0, std::atoi(e))) : (uint32_t)RGK_SAMPLE_GROUP_DEFAULT; }();
-                uint32_t g = want;
+                const char* e = std::getenv("RGK_SAMPLE_GROUP");
+                uint32_t g = e ? (uint32_t)std::min(6, std::max(0, std::atoi(e))) : (uint32_t)RGK_SAMPLE_GROUP_DEFAULT;
                 while (g && (pp.ns & ((1u << g) - 1u))) g--;
                 pp.gshift = g;
             }

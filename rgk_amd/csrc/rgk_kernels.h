@@ -63,6 +63,7 @@ __device__ __forceinline__ uint32_t slot_of(const PassParams& pp, uint32_t j, ui
     return ((((srel >> pp.gshift) * pp.npix) + j) << pp.gshift) | (srel & ((1u << pp.gshift) - 1u));
 }
 
+void rgk_launch_stage_mark(hipStream_t st, uint32_t* host_word, uint32_t v); // progress: the device writes v to pinned host memory
 void rgk_launch_init_counters(hipStream_t st, uint32_t* counters, uint32_t n0);
 void rgk_launch_build_pixel_list(hipStream_t st, const rgk_tile* tiles, const uint32_t* tile_off, uint32_t n_tiles, uint32_t* pix_xy, uint32_t* pix_seed);
 void rgk_launch_build_halton_table(hipStream_t st, const DevScene& sc, uint32_t S, float* htab);

@@ -518,6 +518,8 @@ int rgk_trace_grid(int lds_entries) {
         else { if (count_stats) K<true, 256, 16><<<grid, RGK_TRACE_BLOCK, 0, st>>>(__VA_ARGS__); else K<false, 256, 16><<<grid, RGK_TRACE_BLOCK, 0, st>>>(__VA_ARGS__); } \
     }
 
+__global__ void k_stage_mark(uint32_t* host_word, uint32_t v) { *(volatile uint32_t*)host_word = v; __threadfence_system(); }
+void rgk_launch_stage_mark(hipStream_t st, uint32_t* host_word, uint32_t v) { k_stage_mark<<<1, 1, 0, st>>>(host_word, v); }
 void rgk_launch_init_counters(hipStream_t st, uint32_t* counters, uint32_t n0) { k_init_counters<<<1, 256, 0, st>>>(counters, n0); }
 void rgk_launch_build_pixel_list(hipStream_t st, const rgk_tile* tiles, const uint32_t* tile_off, uint32_t n_tiles, uint32_t* pix_xy, uint32_t* pix_seed) {
     k_build_pixel_list<<<n_tiles < 4096u ? n_tiles : 4096u, 256, 0, st>>>(tiles, tile_off, n_tiles, pix_xy, pix_seed);

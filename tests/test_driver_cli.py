@@ -68,6 +68,16 @@ def test_cli_renders_writes_resumes_and_claims_frames(tmp_path):
     sc = rd.Scene(c.build_scene().to_desc())
     acc, cnt, _ = sc.render_round(c.get_camera(), c.get_params(), rd.generate_task_list(c.xres, c.yres))
     assert np.allclose(vals, acc[30, 40] / cnt[30, 40], rtol=1e-6, atol=0)
+    # ... and the same pixel replayed on the CPU oracle ("-d X Y single-pixel trace replayed on rgk_cpu")
+    from oracle import rgk_oracle
+    from rgk_amd import capi
+    home = next(tl for tl in rd.generate_task_list(c.xres, c.yres) if tl.x0 <= 40 < tl.x1 and tl.y0 <= 30 < tl.y1)
+    one = (capi.Tile * 1)()
+    one[0].x0, one[0].x1, one[0].y0, one[0].y1 = 40, 41, 30, 31
+    one[0].seed = (home.seed + ((30 - home.y0) * (home.x1 - home.x0) + (40 - home.x0)) * 0x42424242) & 0xFFFFFFFF
+    o = rgk_oracle.OracleScene(c.build_scene().to_desc())
+    ao, co, _ = o.render_round(c.get_camera(), c.get_params(), one)
+    assert np.allclose(vals, ao[30, 40] / co[30, 40], rtol=1e-6, atol=0)
     # rotate: frames are claimed by creating the file; an existing frame is skipped (--no-overwrite is implied)
     open(str(tmp_path / "cli.00001.exr"), "wb").close()
     r5 = run_cli([str(cfg), "-D", str(tmp_path), "-r", "--frames", "3", "-q"], str(tmp_path))

@@ -232,6 +232,34 @@ def test_cornell_image_parity(rd, oracle):
     assert kg.shadow_rays <= ko.shadow_rays                                        # zero-radiance shadow rays are skipped
 
 
+def test_slot_order_does_not_change_the_image(rd, oracle):
+    """The order in which (pixel, sample) pairs occupy path slots is free (PassParams::gshift): 1, 4, 8 or 64 samples of a
+    pixel side by side, sample counts that are no multiple of the group (fallback to a smaller group), and passes split over
+    pixels and samples all give the same bits, and the oracle's image."""
+    from rgk_amd.workloads import Workload
+    for spp in (12, 7, 64):
+        wl = Workload("cornell-256", scale=0.25, spp=spp)
+        g = rd.Scene(wl.builder.to_desc())
+        tiles = rd.generate_task_list(wl.xres, wl.yres)
+        imgs = {}
+        for grp, batch in (("0", None), ("2", None), ("3", None), ("6", None), ("3", 20000)):
+            os.environ["RGK_SAMPLE_GROUP"] = grp
+            if batch: os.environ["RGK_BATCH_PATHS"] = str(batch)
+            try:
+                imgs[(grp, batch)], cnt, _ = g.render_round(wl.camera, wl.params(), tiles)
+            finally:
+                del os.environ["RGK_SAMPLE_GROUP"]
+                os.environ.pop("RGK_BATCH_PATHS", None)
+            assert (cnt == spp).all()
+        base = imgs[("0", None)]
+        assert all(np.array_equal(base, v) for v in imgs.values()), spp
+        if spp == 12:
+            o = oracle.OracleScene(wl.builder.to_desc())
+            ref, _, _ = o.render_round(wl.camera, wl.params(), tiles)
+            image_metrics(base, ref, "test_slot_order_does_not_change_the_image")
+            assert np.linalg.norm(base - ref) / np.linalg.norm(ref) <= 1e-3
+
+
 def test_cornell_against_the_frozen_oracle_image(rd):
     """The committed expected accumulator of BASELINE configs[0] at half resolution (tests/golden/cornell_config0_half.npz,
     rendered by the oracle, generator tools/make_fixtures.py): no oracle code runs in this test."""
