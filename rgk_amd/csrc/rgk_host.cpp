@@ -332,7 +332,10 @@ struct DevBuf {
         // RGK_POISON=1: every fresh device buffer is filled with 0xFF bytes (NaN as float, huge as index), so that any read of
         // memory the pipeline did not write first shows in the results instead of hiding behind zero-filled fresh pages
         static const bool poison = std::getenv("RGK_POISON") != nullptr;
-        if (poison) (void)hipMemset(p, 0xFF, count * sizeof(T));
+        if (poison) { // (the fill runs on the null stream, the scene's stream is non-blocking: wait for it, or it lands on top of real data)
+            (void)hipMemset(p, 0xFF, count * sizeof(T));
+            (void)hipDeviceSynchronize();
+        }
         return 0;
     }
     int upload(const std::vector<T>& v) {
