@@ -115,9 +115,11 @@ __device__ __forceinline__ bool clip_to_scene(const DevScene& sc, f3 o, f3 d, fl
 // A wave takes `chunk` consecutive rays per visit to the device-wide cursor.  One returning atomic
 // on a single word sustains only ~88 dequeues/us chip-wide (MI355X guide, price list "dequeue"):
 // at 64 rays per dequeue that alone capped the kernel at ~5.6 G rays/s, so the chunk grows with
-// the queue.
-__device__ __forceinline__ uint32_t fetch_chunk(uint32_t count, uint32_t nwaves) {
-    uint32_t c = (count / (nwaves * 4u)) & ~63u;
+// the queue.  The last piece a wave takes is the launch's tail, so a wave's share comes in `pieces` pieces: 16 for the
+// closest-hit launches (one rank's eighth of a frame: 10.0 -> 9.5 ms per round against 4 pieces), 4 for the shadow launches,
+// whose rays are short enough that 16 pieces ran into the dequeue rate (2.5 -> 3.8 ms).
+__device__ __forceinline__ uint32_t fetch_chunk(uint32_t count, uint32_t nwaves, uint32_t pieces) {
+    uint32_t c = (count / (nwaves * pieces)) & ~63u;
     return c < 64u ? 64u : (c > RGK_CHUNK_MAX ? RGK_CHUNK_MAX : c);
 }
 
@@ -144,7 +146,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
     const int walk_q = (int)sc.walk_q;
     const float4* __restrict__ nodes = reinterpret_cast<const float4*>(sc.nodes);
     const float4* __restrict__ tris = reinterpret_cast<const float4*>(sc.tris);
-    const uint32_t chunk = fetch_chunk(count, gridDim.x * (RGK_TRACE_BLOCK / 64));
+    const uint32_t chunk = fetch_chunk(count, gridDim.x * (RGK_TRACE_BLOCK / 64), ANY ? 4u : 16u);
     uint32_t w_next = 0, w_end = 0; // wave-uniform: this wave's slice of the queue
     bool exhausted = false;         // wave-uniform: the device cursor has passed `count`
     // per-lane ray state
