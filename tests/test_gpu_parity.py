@@ -447,6 +447,33 @@ def test_bidirectional_reverse_parity(rd, oracle):
 FULL_SIZE_SPONZA_REL, FULL_SIZE_SPONZA_WITHIN = 1e-3, 0.999   # SURVEY 8(d)'s gate, on the benchmark workload at full size (measured 2.2e-4 / 0.9993)
 
 
+def test_cornell_config2_full_size_256spp(rd, oracle):
+    """BASELINE configs[1] as quoted: cornell-box 1024 x 1024 x 256 spp, russian 0.75 (268 M paths).  Whole frame: counts,
+    range, idempotence, the two-halves deal; 64 tiles of it (16.8 M paths) against the oracle at the full sample count."""
+    from rgk_amd.workloads import Workload
+    wl = Workload("cornell-1024")
+    assert (wl.xres, wl.yres, wl.multisample) == (1024, 1024, 256) and abs(wl.russian - 0.75) < 1e-6
+    g = rd.Scene(wl.builder.to_desc())
+    prm = wl.params()
+    tiles = rd.generate_task_list(wl.xres, wl.yres)
+    acc, cnt, k = g.render_round(wl.camera, prm, tiles)
+    assert (cnt == 256).all() and k.paths == 1024 * 1024 * 256
+    assert np.isfinite(acc).all() and (acc >= 0).all() and acc.max() <= 256 * wl.clamp * (1 + 1e-6)
+    a3 = np.zeros_like(acc); c3 = np.zeros_like(cnt)
+    ev = (capi.Tile * ((len(tiles) + 1) // 2))(*tiles[0::2]); od = (capi.Tile * (len(tiles) // 2))(*tiles[1::2])
+    g.render_round(wl.camera, prm, ev, a3, c3); g.render_round(wl.camera, prm, od, a3, c3)
+    assert np.array_equal(acc, a3) and np.array_equal(cnt, c3)
+    sub = (capi.Tile * 64)(*tiles[:64])
+    o = oracle.OracleScene(wl.builder.to_desc())
+    ao = np.zeros_like(acc); co = np.zeros_like(cnt); o.render_round(wl.camera, prm, sub, ao, co)
+    m = co > 0
+    assert m.sum() == 64 * 1024 and np.array_equal(cnt[m], co[m])
+    d = np.linalg.norm(acc[m] - ao[m], axis=1); r = np.linalg.norm(ao[m], axis=1)
+    rel = float(np.linalg.norm(acc[m] - ao[m]) / np.linalg.norm(ao[m])); within = float((d <= np.maximum(1e-3 * r, 1e-6)).mean())
+    record_parity("test_cornell_config2_full_size_256spp", rel_l2_64_tiles=rel, within_1e3=within, bit_identical=float((d == 0).mean()), size="1024x1024x256")
+    assert rel <= 1e-3 and within >= 0.999
+
+
 def test_round_properties_cornell_config2_size(rd, oracle):
     """BASELINE configs[1] geometry at 1024x1024 (16 spp to stay quick): size-independent properties."""
     from rgk_amd.workloads import Workload
