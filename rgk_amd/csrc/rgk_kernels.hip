@@ -13,6 +13,7 @@
 // bounce's queue with a wave ballot + prefix popcount and one atomic per workgroup.
 // No MFMA: there is no dense contraction on this path.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "rgk_device.h"
 #include "rgk_kernels.h"
 
@@ -500,6 +501,8 @@ static inline int bounded_grid(int full, uint32_t items, uint32_t per_block) {
 int rgk_trace_grid(int lds_entries) {
     // LDS-limited residency: entries*256*4 B per block out of 160 KiB, 256 CUs
     int per_cu = (160 * 1024) / (lds_entries * RGK_TRACE_BLOCK * 4);
+    static const int cap = [] { const char* e = std::getenv("RGK_TRACE_PER_CU"); return e ? std::atoi(e) : 8; }(); // experiments: leave room for a second stream
+    if (per_cu > cap) per_cu = cap;
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
     return 256 * per_cu;
