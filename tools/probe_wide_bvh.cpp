@@ -1,0 +1,156 @@
+// Probe: node visits per ray of a 4-wide BVH with distance-sorted children (what the product walks) against an 8-wide BVH
+// walked in octant order (slot ^ ~octant, one stack entry per node) and in distance order, on the Sponza proxy.
+// g++ -O2 -std=c++17 probe.cpp -o probe && ./probe tris.bin rays.bin
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <random>
+#include <vector>
+struct V3 { float x, y, z; };
+static inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+static inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+static inline V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+static inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+static inline float comp(V3 v, int i) { return i == 0 ? v.x : i == 1 ? v.y : v.z; }
+struct Box { V3 lo{1e30f, 1e30f, 1e30f}, hi{-1e30f, -1e30f, -1e30f};
+    void add(V3 p) { lo = {std::min(lo.x, p.x), std::min(lo.y, p.y), std::min(lo.z, p.z)}; hi = {std::max(hi.x, p.x), std::max(hi.y, p.y), std::max(hi.z, p.z)}; }
+    void add(const Box& b) { add(b.lo); add(b.hi); }
+    float area() const { V3 d = hi - lo; return 2 * (d.x * d.y + d.y * d.z + d.z * d.x); }
+    V3 c() const { return (lo + hi) * 0.5f; } };
+struct Tri { V3 a, b, c; };
+struct N2 { Box box; int l = -1, r = -1, first = 0, cnt = 0; };
+std::vector<Tri> T; std::vector<int> order; std::vector<N2> n2;
+std::vector<Box> tb;
+int build(int b, int e) {
+    N2 n; for (int i = b; i < e; i++) n.box.add(tb[order[i]]);
+    int id = (int)n2.size(); n2.push_back(n);
+    int cnt = e - b;
+    if (cnt <= 4) {
+        // SAH leaf test
+    }
+    float best = 1e30f; int bax = -1, bsplit = 0; const int NB = 16;
+    Box cb; for (int i = b; i < e; i++) cb.add(tb[order[i]].c());
+    for (int ax = 0; ax < 3; ax++) {
+        float lo = comp(cb.lo, ax), hi = comp(cb.hi, ax); if (hi - lo < 1e-9f) continue;
+        Box bb[NB]; int bc[NB] = {0};
+        for (int i = b; i < e; i++) { int k = std::min(NB - 1, (int)((comp(tb[order[i]].c(), ax) - lo) / (hi - lo) * NB)); bb[k].add(tb[order[i]]); bc[k]++; }
+        float la[NB], ra[NB]; int lc[NB], rc[NB]; Box acc; int c = 0;
+        for (int k = 0; k < NB; k++) { if (bc[k]) acc.add(bb[k]); c += bc[k]; la[k] = c ? acc.area() : 0; lc[k] = c; }
+        acc = Box(); c = 0;
+        for (int k = NB - 1; k >= 0; k--) { if (bc[k]) acc.add(bb[k]); c += bc[k]; ra[k] = c ? acc.area() : 0; rc[k] = c; }
+        for (int k = 0; k < NB - 1; k++) { if (!lc[k] || !rc[k + 1]) continue; float cost = la[k] * lc[k] + ra[k + 1] * rc[k + 1]; if (cost < best) { best = cost; bax = ax; bsplit = k; } }
+    }
+    if (bax < 0 || (cnt <= 4 && best / n2[id].box.area() + 1.0f >= (float)cnt)) { n2[id].first = b; n2[id].cnt = cnt; if (cnt > 4 && bax < 0) { /* fall through to median */ } else return id; }
+    int mid;
+    if (bax >= 0) {
+        float lo = comp(cb.lo, bax), hi = comp(cb.hi, bax);
+        mid = (int)(std::partition(order.begin() + b, order.begin() + e, [&](int t) { return std::min(NB - 1, (int)((comp(tb[t].c(), bax) - lo) / (hi - lo) * NB)) <= bsplit; }) - order.begin());
+    } else mid = (b + e) / 2;
+    if (mid == b || mid == e) mid = (b + e) / 2;
+    n2[id].cnt = 0;
+    int l = build(b, mid); int r = build(mid, e);
+    n2[id].l = l; n2[id].r = r;
+    return id;
+}
+// wide node
+struct NW { Box box[8]; int child[8]; int n = 0; };  // child >= 0: wide node index; < 0: ~leaf n2 index
+std::vector<NW> wide;
+int collapse(int root2, int width, bool slots) {
+    std::vector<int> open{root2};
+    // open the largest-area inner child until `width` children
+    for (;;) {
+        if ((int)open.size() >= width) break;
+        int bi = -1; float ba = -1;
+        for (int i = 0; i < (int)open.size(); i++) if (n2[open[i]].l >= 0 && n2[open[i]].box.area() > ba) { ba = n2[open[i]].box.area(); bi = i; }
+        if (bi < 0) break;
+        int n = open[bi]; open[bi] = n2[n].l; open.push_back(n2[n].r);
+    }
+    int id = (int)wide.size(); wide.emplace_back();
+    // slot assignment (8-wide): greedy by |dot(centroid offset, octant direction)|
+    std::vector<int> slot(open.size(), -1);
+    if (slots && width == 8) {
+        Box nb; for (int c : open) nb.add(n2[c].box);
+        V3 nc = nb.c();
+        std::vector<std::array<float, 3>> cand; // (score, child, slot)
+        std::vector<bool> usedc(open.size(), false), useds(8, false);
+        for (int k = 0; k < (int)open.size(); k++) {
+            float bs = -1e30f; int bc = -1, bsl = -1;
+            for (int c = 0; c < (int)open.size(); c++) if (!usedc[c]) for (int s = 0; s < 8; s++) if (!useds[s]) {
+                V3 d = n2[open[c]].box.c() - nc; V3 dir{(s & 1) ? 1.f : -1.f, (s & 2) ? 1.f : -1.f, (s & 4) ? 1.f : -1.f};
+                float sc = dot(d, dir); if (sc > bs) { bs = sc; bc = c; bsl = s; }
+            }
+            usedc[bc] = true; useds[bsl] = true; slot[bc] = bsl;
+        }
+    } else for (int c = 0; c < (int)open.size(); c++) slot[c] = c;
+    NW w; for (int s = 0; s < 8; s++) w.child[s] = INT32_MIN;
+    w.n = (int)open.size();
+    wide[id] = w;
+    for (int c = 0; c < (int)open.size(); c++) {
+        int n = open[c];
+        wide[id].box[slot[c]] = n2[n].box;
+        int ch = n2[n].l < 0 ? ~n : collapse(n, width, slots);
+        wide[id].child[slot[c]] = ch;
+    }
+    return id;
+}
+static bool tri_hit(const Tri& t, V3 o, V3 d, float& tt) {
+    V3 e1 = t.b - t.a, e2 = t.c - t.a, p = cross(d, e2); float det = dot(e1, p); if (std::fabs(det) < 1e-12f) return false;
+    float inv = 1 / det; V3 s = o - t.a; float u = dot(s, p) * inv; if (u < 0 || u > 1) return false;
+    V3 q = cross(s, e1); float v = dot(d, q) * inv; if (v < 0 || u + v > 1) return false;
+    tt = dot(e2, q) * inv; return tt > 1e-4f;
+}
+static bool slab(const Box& b, V3 o, V3 inv, float tmax, float& tn) {
+    float t0 = 0, t1 = tmax;
+    for (int a = 0; a < 3; a++) { float x0 = (comp(b.lo, a) - comp(o, a)) * comp(inv, a), x1 = (comp(b.hi, a) - comp(o, a)) * comp(inv, a); if (x0 > x1) std::swap(x0, x1); t0 = std::max(t0, x0); t1 = std::min(t1, x1); }
+    tn = t0; return t0 <= t1;
+}
+struct Stat { double nodes = 0, tris = 0, rays = 0; };
+// mode 0: distance order; 1: octant order (slot ^ ~oct descending)
+float trace(int root, V3 o, V3 d, int mode, Stat& st, int* hit_tri) {
+    V3 inv{1 / d.x, 1 / d.y, 1 / d.z}; int oct = (d.x < 0) | ((d.y < 0) << 1) | ((d.z < 0) << 2);
+    float best = 1e30f; int bt = -1; std::vector<int> stack{root};
+    while (!stack.empty()) {
+        int n = stack.back(); stack.pop_back();
+        if (n < 0) { const N2& lf = n2[~n]; for (int i = 0; i < lf.cnt; i++) { st.tris++; float t; if (tri_hit(T[order[lf.first + i]], o, d, t) && t < best) { best = t; bt = order[lf.first + i]; } } continue; }
+        st.nodes++;
+        const NW& w = wide[n];
+        struct E { float t; int c; int key; } e[8]; int ne = 0;
+        for (int s = 0; s < 8; s++) { if (w.child[s] == INT32_MIN) continue; float tn; if (slab(w.box[s], o, inv, best, tn)) e[ne++] = {tn, w.child[s], s ^ (7 - oct)}; }
+        if (mode == 0) std::sort(e, e + ne, [](const E& a, const E& b) { return a.t > b.t; });           // far first (pushed), near popped first
+        else std::sort(e, e + ne, [](const E& a, const E& b) { return a.key < b.key; });                 // low priority first
+        for (int i = 0; i < ne; i++) stack.push_back(e[i].c);
+    }
+    st.rays++; if (hit_tri) *hit_tri = bt; return best;
+}
+int main(int argc, char** argv) {
+    FILE* f = fopen(argv[1], "rb"); fseek(f, 0, SEEK_END); long sz = ftell(f); fseek(f, 0, SEEK_SET); T.resize(sz / 36); if (fread(T.data(), 36, T.size(), f) != T.size()) return 1; fclose(f);
+    f = fopen(argv[2], "rb"); fseek(f, 0, SEEK_END); sz = ftell(f); fseek(f, 0, SEEK_SET); std::vector<std::array<float, 6>> R(sz / 24); if (fread(R.data(), 24, R.size(), f) != R.size()) return 1; fclose(f);
+    tb.resize(T.size()); order.resize(T.size());
+    for (size_t i = 0; i < T.size(); i++) { tb[i].add(T[i].a); tb[i].add(T[i].b); tb[i].add(T[i].c); order[i] = (int)i; }
+    int r2 = build(0, (int)T.size());
+    printf("bvh2 nodes %zu\n", n2.size());
+    std::mt19937 rng(1); std::uniform_real_distribution<float> U(0, 1);
+    for (int cfg = 0; cfg < 4; cfg++) {
+        int width = cfg == 0 ? 4 : 8; int mode = cfg <= 1 ? 0 : 1; bool slots = cfg == 3 || cfg == 2;
+        if (cfg == 2) slots = false; // octant order WITHOUT octant-aware slots: what not to do
+        wide.clear(); int root = collapse(r2, width, slots);
+        Stat cam, bnc; std::vector<std::array<float, 6>> B;
+        rng.seed(1);
+        for (auto& r : R) {
+            V3 o{r[0], r[1], r[2]}, d{r[3], r[4], r[5]}; int ht; float t = trace(root, o, d, mode, cam, &ht);
+            if (ht >= 0) { const Tri& tr = T[ht]; V3 n = cross(tr.b - tr.a, tr.c - tr.a); float l = std::sqrt(dot(n, n)); n = n * (1 / l); if (dot(n, d) > 0) n = n * -1.f;
+                V3 p = o + d * t + n * 1e-3f; float u1 = U(rng), u2 = U(rng); float rr = std::sqrt(u1), ph = 6.2831853f * u2;
+                V3 a = std::fabs(n.x) > 0.9f ? V3{0, 1, 0} : V3{1, 0, 0}; V3 t1 = cross(n, a); t1 = t1 * (1 / std::sqrt(dot(t1, t1))); V3 t2 = cross(n, t1);
+                V3 bd = t1 * (rr * std::cos(ph)) + t2 * (rr * std::sin(ph)) + n * std::sqrt(std::max(0.f, 1 - u1)); B.push_back({p.x, p.y, p.z, bd.x, bd.y, bd.z}); }
+        }
+        for (auto& r : B) trace(root, {r[0], r[1], r[2]}, {r[3], r[4], r[5]}, mode, bnc, nullptr);
+        printf("width %d %s%s: wide nodes %zu | camera rays: %.2f nodes %.2f tris per ray | bounce rays: %.2f nodes %.2f tris per ray\n", width, mode ? "octant order" : "distance order", slots ? " (octant slots)" : "",
+               wide.size(), cam.nodes / cam.rays, cam.tris / cam.rays, bnc.nodes / bnc.rays, bnc.tris / bnc.rays);
+    }
+    return 0;
+}
