@@ -21,6 +21,8 @@
 #include <limits>
 #include <string>
 #include <vector>
+#include <functional>
+#include <random>
 
 #include "../../include/rgk.h"
 #include "device_types.h"
@@ -236,6 +238,107 @@ struct BvhBuilder {
         return idx;
     }
 };
+
+// ------------------------------------------------------------------ BVH2 optimisation by reinsertion
+// The binned top-down build decides every split with local information; afterwards single subtrees are taken out and put back
+// where the surface-area cost of the whole tree grows least (insertion-based optimisation, Bittner, Hapala, Havran 2013, in its
+// simplest form: the largest nodes first, branch-and-bound search from the root).  Same triangles, same leaves, so the same
+// hits; on the Sponza proxy 8 rounds over half of the nodes cut the surface-area cost by 4 % and the node visits per ray by
+// 4 % (diffuse bounce rays) to 9 % (camera rays) -- tools/probe_wide_bvh.py measures it on the CPU.
+static void optimise_bvh2(std::vector<BvhNode>& nodes, std::vector<uint32_t>& order, int rounds, float frac) {
+    const int NI = (int)nodes.size();
+    if (NI < 8 || rounds <= 0) return;
+    std::vector<Box> box; std::vector<int> l, r, par, leaf_code;
+    box.reserve(2 * NI + 1); l.assign(NI, -1); r.assign(NI, -1);
+    box.resize(NI);
+    auto side_box = [](const BvhNode& n, bool left) { Box b; for (int a = 0; a < 3; a++) { b.mn[a] = left ? n.lmin[a] : n.rmin[a]; b.mx[a] = left ? n.lmax[a] : n.rmax[a]; } return b; };
+    for (int i = 0; i < NI; i++) {
+        for (int sd = 0; sd < 2; sd++) {
+            const int code = sd == 0 ? nodes[i].left : nodes[i].right;
+            const Box b = side_box(nodes[i], sd == 0);
+            int id;
+            if (code >= 0) { id = code; box[id] = b; }
+            else { id = (int)box.size(); box.push_back(b); l.push_back(-1); r.push_back(-1); leaf_code.resize(box.size(), 0); leaf_code[id] = code; }
+            (sd == 0 ? l[i] : r[i]) = id;
+        }
+    }
+    leaf_code.resize(box.size(), 0);
+    const int N = (int)box.size();
+    par.assign(N, -1);
+    for (int i = 0; i < NI; i++) { par[l[i]] = i; par[r[i]] = i; }
+    box[0] = box[l[0]]; box[0].grow(box[r[0]]);
+    auto refit_up = [&](int n) { while (n >= 0) { Box b = box[l[n]]; b.grow(box[r[n]]); box[n] = b; n = par[n]; } };
+    std::mt19937 rng(7);
+    const auto heap_cmp = [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a.first > b.first; };
+    std::vector<std::pair<float, int>> pq;
+    for (int it = 0; it < rounds; it++) {
+        std::vector<int> cand;
+        const auto larger = [&](int a, int b) { const float x = box[a].area(), y = box[b].area(); return x > y || (x == y && a < b); };
+        if (!(it & 1)) { // the largest nodes (they cost the most); bounded work per round: a 1 M-triangle tree moves its largest nodes only
+            for (int i = 1; i < N; i++) if (par[i] > 0) cand.push_back(i);
+            const size_t take = std::min<size_t>((size_t)(cand.size() * frac), 65536);
+            std::nth_element(cand.begin(), cand.begin() + take, cand.end(), larger);
+            cand.resize(take);
+            std::sort(cand.begin(), cand.end(), larger);
+        } else { // every other round: any nodes
+            const size_t take = std::min<size_t>((size_t)(N * frac), 65536);
+            for (size_t k = 0; k < take; k++) { const int i = (int)(rng() % (uint32_t)N); if (par[i] > 0) cand.push_back(i); }
+        }
+        for (int n : cand) {
+            const int p = par[n];
+            if (p <= 0) continue;
+            const int g = par[p];
+            const int sib = l[p] == n ? r[p] : l[p];
+            (l[g] == p ? l[g] : r[g]) = sib; // n and its parent leave the tree: the sibling moves up
+            par[sib] = g;
+            refit_up(g);
+            const Box nb = box[n];
+            const float na = nb.area();
+            float best = std::numeric_limits<float>::infinity();
+            int bx = sib;
+            pq.clear(); pq.push_back({0.f, 0});
+            while (!pq.empty()) {
+                std::pop_heap(pq.begin(), pq.end(), heap_cmp);
+                const float ind = pq.back().first; const int x = pq.back().second;
+                pq.pop_back();
+                if (ind + na >= best) break;
+                Box u = box[x]; u.grow(nb);
+                const float total = ind + u.area();
+                if (total < best && par[x] >= 0) { best = total; bx = x; } // (not above the root: node 0 stays the root)
+                const float child_ind = total - box[x].area();
+                if (l[x] >= 0 && child_ind + na < best) {
+                    pq.push_back({child_ind, l[x]}); std::push_heap(pq.begin(), pq.end(), heap_cmp);
+                    pq.push_back({child_ind, r[x]}); std::push_heap(pq.begin(), pq.end(), heap_cmp);
+                }
+            }
+            const int xp = par[bx]; // p becomes the parent of (bx, n) where bx was
+            (l[xp] == bx ? l[xp] : r[xp]) = p;
+            par[p] = xp; l[p] = bx; r[p] = n; par[bx] = p; par[n] = p;
+            refit_up(p);
+        }
+    }
+    // back to the builder's form: inner nodes in depth-first order from node 0, leaves re-listed in that order
+    std::vector<BvhNode> out; out.reserve(NI);
+    std::vector<uint32_t> new_order; new_order.reserve(order.size());
+    std::function<int(int)> emit = [&](int n) -> int {
+        if (l[n] < 0) {
+            const uint32_t code = ~(uint32_t)leaf_code[n], first = code >> 4, cnt = (code & 15u) + 1u;
+            const uint32_t nf = (uint32_t)new_order.size();
+            for (uint32_t k = 0; k < cnt; k++) new_order.push_back(order[first + k]);
+            return (int)~((nf << 4) | (cnt - 1));
+        }
+        const int idx = (int)out.size();
+        out.emplace_back();
+        const int a = emit(l[n]), b = emit(r[n]);
+        BvhNode& nd = out[idx];
+        for (int k = 0; k < 3; k++) { nd.lmin[k] = box[l[n]].mn[k]; nd.lmax[k] = box[l[n]].mx[k]; nd.rmin[k] = box[r[n]].mn[k]; nd.rmax[k] = box[r[n]].mx[k]; }
+        nd.left = a; nd.right = b; nd.pad[0] = nd.pad[1] = 0;
+        return idx;
+    };
+    emit(0);
+    nodes.swap(out);
+    order.swap(new_order);
+}
 
 // ------------------------------------------------------------------ BVH2 -> quantised BVH4
 // Collapse the binary tree (always open the inner child with the largest surface until four
@@ -726,6 +829,8 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
             bb.nodes.pop_back();
             code = bb.build(0, prims.size(), 0, rootbox);
             if (code != 0) return fail(RGK_ERR_DEVICE, "internal: BVH root is not node 0");
+            const char* e = std::getenv("RGK_BVH_OPT"); // reinsertion rounds (0 = off)
+            optimise_bvh2(bb.nodes, bb.order, e ? std::atoi(e) : 8, 0.5f);
         }
         nodes.swap(bb.nodes);
         leaf_recs.reserve(bb.order.size());

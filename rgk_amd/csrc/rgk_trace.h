@@ -328,7 +328,13 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
                 float t, al, be;
                 if (tri_test(r0, r1, r2, o, d, eps, t, al, be)) {
                     if (t < tlo || t > thi) continue;
-                    if (t < best_t) { best_t = t; best_tri = (int)tid; best_a = al; best_b = be; if (ANY) done = true; }
+                    // Exact ties go to the HIGHER triangle id, so that the result does not depend on the order in which this walker
+                    // happens to reach the leaves (it changes with every change to the tree builder).  The reference takes the first
+                    // triangle of its kd leaf's list (strict <, src/scene_intersect.cpp:272-284), and that list is in the order of
+                    // an unstable sort of box events (src/scene.cpp:459-468): no rule of its own.  Coplanar overlapping surfaces do
+                    // tie -- the Cornell lights lie IN the ceiling -- and there "higher id" is what the reference's build yields
+                    // (300 k random rays, four different trees: test_closest_hit_cornell_bit_exact).
+                    if (t < best_t || (!ANY && t == best_t && tid > (uint32_t)best_tri && best_tri >= 0)) { best_t = t; best_tri = (int)tid; best_a = al; best_b = be; if (ANY) done = true; }
                 }
             }
             if (ANY && done) { cur = STACK_SENTINEL; sp = 0; }

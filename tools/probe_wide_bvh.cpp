@@ -57,6 +57,60 @@ int build(int b, int e) {
     n2[id].l = l; n2[id].r = r;
     return id;
 }
+
+// ---- insertion-based optimisation of the BVH2 (Bittner et al. 2013, simplified): take a node out, put it back where the
+// surface-area cost of the tree grows least.
+std::vector<int> par;
+static void refit_up(int n) { while (n >= 0) { Box b = n2[n2[n].l].box; b.add(n2[n2[n].r].box); n2[n].box = b; n = par[n]; } }
+static double sah_cost() { double c = 0; double ra = n2[0].box.area(); for (auto& n : n2) c += (n.l >= 0 ? 1.0 : (double)n.cnt) * n.box.area() / ra; return c; }
+static void optimise(int rounds, float frac) {
+    par.assign(n2.size(), -1);
+    for (int i = 0; i < (int)n2.size(); i++) if (n2[i].l >= 0) { par[n2[i].l] = i; par[n2[i].r] = i; }
+    std::mt19937 rng(7);
+    for (int it = 0; it < rounds; it++) {
+        std::vector<int> cand;
+        for (int i = 1; i < (int)n2.size(); i++) if (par[i] > 0) cand.push_back(i);
+        // the nodes with the largest area first (they cost the most), a fraction of them per round
+        std::sort(cand.begin(), cand.end(), [&](int a, int b) { return n2[a].box.area() > n2[b].box.area(); });
+        size_t take = (size_t)(cand.size() * frac);
+        if (it & 1) { std::shuffle(cand.begin(), cand.end(), rng); }
+        cand.resize(take);
+        for (int n : cand) {
+            int p = par[n]; if (p <= 0) continue; int g = par[p]; if (g < 0) continue;
+            int s = n2[p].l == n ? n2[p].r : n2[p].l;
+            // take n (and p) out: s moves up
+            if (n2[g].l == p) n2[g].l = s; else n2[g].r = s;
+            par[s] = g; refit_up(g);
+            // best place: branch and bound over (induced cost so far) + area(union)
+            const Box nb = n2[n].box; const float na = nb.area();
+            float best = 1e30f; int bx = -1;
+            std::vector<std::pair<float, int>> pq{{0.f, 0}};
+            while (!pq.empty()) {
+                std::pop_heap(pq.begin(), pq.end(), [](auto& a, auto& b) { return a.first > b.first; });
+                auto [ind, x] = pq.back(); pq.pop_back();
+                if (ind + na >= best) break;
+                Box u = n2[x].box; u.add(nb);
+                const float direct = u.area(), total = ind + direct;
+                if (total < best) { best = total; bx = x; }
+                const float child_ind = total - n2[x].box.area();
+                if (n2[x].l >= 0 && child_ind + na < best) {
+                    pq.push_back({child_ind, n2[x].l}); std::push_heap(pq.begin(), pq.end(), [](auto& a, auto& b) { return a.first > b.first; });
+                    pq.push_back({child_ind, n2[x].r}); std::push_heap(pq.begin(), pq.end(), [](auto& a, auto& b) { return a.first > b.first; });
+                }
+            }
+            // put it back: p becomes the parent of (bx, n) where bx was
+            int xp = par[bx];
+            if (xp < 0) { // bx is the root: keep node 0 the root by swapping contents
+                bx = s; xp = par[bx]; // fall back: restore
+            }
+            if (n2[xp].l == bx) n2[xp].l = p; else n2[xp].r = p;
+            par[p] = xp; n2[p].l = bx; n2[p].r = n; n2[p].cnt = 0; par[bx] = p; par[n] = p;
+            refit_up(p);
+        }
+        fprintf(stderr, "  optimise round %d: SAH cost %.3f\n", it, sah_cost());
+    }
+}
+
 // wide node
 struct NW { Box box[8]; int child[8]; int n = 0; };  // child >= 0: wide node index; < 0: ~leaf n2 index
 std::vector<NW> wide;
@@ -133,9 +187,11 @@ int main(int argc, char** argv) {
     tb.resize(T.size()); order.resize(T.size());
     for (size_t i = 0; i < T.size(); i++) { tb[i].add(T[i].a); tb[i].add(T[i].b); tb[i].add(T[i].c); order[i] = (int)i; }
     int r2 = build(0, (int)T.size());
-    printf("bvh2 nodes %zu\n", n2.size());
+    printf("bvh2 nodes %zu, SAH cost %.3f\n", n2.size(), sah_cost());
+    const int opt_rounds = argc > 3 ? atoi(argv[3]) : 0;
+    if (opt_rounds) { optimise(opt_rounds, argc > 4 ? (float)atof(argv[4]) : 0.25f); printf("after %d reinsertion rounds: SAH cost %.3f\n", opt_rounds, sah_cost()); }
     std::mt19937 rng(1); std::uniform_real_distribution<float> U(0, 1);
-    for (int cfg = 0; cfg < 4; cfg++) {
+    for (int cfg = 0; cfg < (opt_rounds ? 1 : 4); cfg++) {
         int width = cfg == 0 ? 4 : 8; int mode = cfg <= 1 ? 0 : 1; bool slots = cfg == 3 || cfg == 2;
         if (cfg == 2) slots = false; // octant order WITHOUT octant-aware slots: what not to do
         wide.clear(); int root = collapse(r2, width, slots);
