@@ -490,6 +490,7 @@ struct rgk_scene {
     DevBuf<float> htab;
     DevBuf<float2> nearfar;
     DevBuf<uint32_t> counters, pix_xy, pix_seed, tile_buf;
+    DevBuf<int> entry; // RGK_ENTRY_K traversal entry nodes per group of 64 pixels of the round's list
     DevBuf<unsigned long long> stats;
     DevBuf<float> scratch_f;
     DevBuf<uint32_t> scratch_u;
@@ -510,7 +511,7 @@ struct rgk_scene {
         for (int i = 0; i < 2; i++) { rayA[i].release(); rayB[i].release(); }
         hit.release(); thr.release(); tot.release(); shA.release(); shB.release(); shC.release(); pixsum.release();
         light.release(); generic.release(); htab.release(); lstart.release(); lv.release(); term.release(); vfin.release(); vemit.release();
-        nearfar.release(); counters.release(); pix_xy.release(); pix_seed.release(); tile_buf.release(); stats.release();
+        nearfar.release(); counters.release(); pix_xy.release(); pix_seed.release(); tile_buf.release(); stats.release(); entry.release();
         scratch_f.release(); scratch_u.release();
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -841,9 +842,9 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
         qnodes.swap(qb.out);
         max_depth = qb.max_depth; max_stack = qb.max_stack; n_nodes = (uint32_t)qnodes.size(); n_refs = (uint32_t)leaf_recs.size();
     }
-    if (max_stack + 1 > 256) return fail(RGK_ERR_UNSUPPORTED, "BVH needs %u traversal-stack entries (max 256)", max_stack + 1);
+    if (max_stack + 1 + RGK_ENTRY_K > 256) return fail(RGK_ERR_UNSUPPORTED, "BVH needs %u traversal-stack entries (max 256)", max_stack + 1);
     {   // traversal stack: 16 entries per lane in LDS + per-lane overflow in global memory (rgk_kernels.hip RGK_TRACE_DISPATCH)
-        const int need = (int)max_stack + 1;
+        const int need = (int)max_stack + 1 + RGK_ENTRY_K; // (+ the entry nodes a camera ray starts with)
         const char* e = std::getenv("RGK_STACK_OVF");
         const char* l = std::getenv("RGK_STACK_LDS");
         if (e && e[0] == '0' && need <= 32) { s->tcfg.stack = 32; s->tcfg.lds = 32; }
@@ -1134,6 +1135,13 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
         HIPCHK(hipMemcpyAsync(s->tile_buf.p, tiles, (size_t)n_tiles * sizeof(rgk_tile), hipMemcpyHostToDevice, st0));
         HIPCHK(hipMemcpyAsync(s->tile_buf.p + (size_t)n_tiles * 5, toff.data(), (n_tiles + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st0));
         rgk_launch_build_pixel_list(st0, reinterpret_cast<const rgk_tile*>(s->tile_buf.p), s->tile_buf.p + (size_t)n_tiles * 5, n_tiles, s->pix_xy.p, s->pix_seed.p);
+        const char* ee = std::getenv("RGK_ENTRY_POINTS"); // 0: every camera ray starts at the root
+        if (!(ee && ee[0] == '0')) {
+            if ((rc = s->entry.alloc(((size_t)P + RGK_ENTRY_PIX - 1) / RGK_ENTRY_PIX * RGK_ENTRY_K))) return rc;
+            DevCamera cam0;
+            make_camera(camera, cam0);
+            rgk_launch_entry_points(st0, s->dev, cam0, prm->xres, prm->yres, s->pix_xy.p, (uint32_t)P, s->entry.p);
+        } else s->entry.release();
     }
     // no light at all: TracePath builds no light sub-path (`reverse > 0 && valid light`), same as reverse == 0
     const uint32_t R = (s->dev.total_point_power + s->dev.total_areal_power > 0.0f) ? prm->reverse : 0u;
@@ -1202,6 +1210,7 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
     pp.lstart = s->lstart.p; pp.lv = s->lv.p; pp.term = s->term.p; pp.vfin = s->vfin.p; pp.vemit = s->vemit.p;
     pp.batch = (uint32_t)s->batch;
     pp.pix_xy = s->pix_xy.p; pp.pix_seed = s->pix_seed.p;
+    pp.entry = s->entry.p; // (null when switched off; only the unidirectional bounce-0 launch reads it)
     if ((rc = s->htab.alloc((size_t)192 * prm->multisample))) return rc;
     TIMED(3, rgk_launch_build_halton_table(st, s->dev, prm->multisample, s->htab.p));
     pp.htab = s->htab.p; pp.light = s->light.p; pp.generic = s->generic.p;

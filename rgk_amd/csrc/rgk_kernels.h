@@ -28,6 +28,14 @@
 #define RGK_SHADOW_CELL 1  // cells[target] = radiance                  (BDPT: term[q][slot])
 #define RGK_SHADOW_SPLAT 2 // atomicAdd(accum_rgb[pixel], radiance)     (BDPT: light-tracing side effect)
 
+#ifndef RGK_ENTRY_K
+#define RGK_ENTRY_K 6 // entry nodes per pixel group (unused ones hold the traversal's stack sentinel)
+#endif
+#ifndef RGK_ENTRY_SHIFT
+#define RGK_ENTRY_SHIFT 3 // log2 of the pixels per group: consecutive pixels of the round's list (8x8 blocks, row-major inside: a row of 8)
+// (Sponza proxy, ms per round: off 146.6; K, pixels = 4, 64: 138.8; 8, 64: 137.5; 4, 16: 139.4; 4, 8: 139.1; 6, 8: 136.3; 8, 8: 136.2)
+#endif
+#define RGK_ENTRY_PIX (1u << RGK_ENTRY_SHIFT)
 // One pass = pixels [j0, j0+npix) of the round's pixel list x samples [s0, s0+ns).
 // Path slot = ((srel >> g) * npix + j) << g | (srel & (2^g - 1)) with srel = s - s0, j = pixel - j0, g = gshift: 2^g consecutive
 // samples of a pixel sit side by side, so a wave of 64 slots is 64 >> g neighbouring pixels x 2^g samples -- rays that differ by
@@ -43,6 +51,7 @@ struct PassParams {
     const uint32_t* pix_seed; // PathTracer::samplerSeed for that pixel (a2)
     const float* htab;        // halton_raw(hdim, s) for hdim < 192, s < multisample: htab[hdim * multisample + s]
     float4* light;            // per slot: the path's light {pos.xyz, code}, written by the first vertex of a path that goes on
+    const int* entry;         // camera rays: RGK_ENTRY_K node refs per group of RGK_ENTRY_PIX consecutive pixels of the round's list (k_entry_points), or null
     // bidirectional state (reverse > 0), null otherwise; per slot with stride `batch`
     float4* lstart;           // light_at_path_start.rgb
     float4* lv;               // light vertices: lv[(k*RGK_LV_FLOAT4 + c) * batch + slot], c: see RGK_LV_FLOAT4
@@ -63,6 +72,7 @@ __device__ __forceinline__ uint32_t slot_of(const PassParams& pp, uint32_t j, ui
     return ((((srel >> pp.gshift) * pp.npix) + j) << pp.gshift) | (srel & ((1u << pp.gshift) - 1u));
 }
 
+void rgk_launch_entry_points(hipStream_t st, const DevScene& sc, const DevCamera& cam, uint32_t xres, uint32_t yres, const uint32_t* pix_xy, uint32_t n_pixels, int* entries);
 void rgk_launch_stage_mark(hipStream_t st, uint32_t* host_word, uint32_t v); // progress: the device writes v to pinned host memory
 void rgk_launch_init_counters(hipStream_t st, uint32_t* counters, uint32_t n0);
 void rgk_launch_build_pixel_list(hipStream_t st, const rgk_tile* tiles, const uint32_t* tile_off, uint32_t n_tiles, uint32_t* pix_xy, uint32_t* pix_seed);

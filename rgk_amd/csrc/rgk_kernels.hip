@@ -521,6 +521,87 @@ int rgk_trace_grid(int lds_entries) {
         else { if (count_stats) K<true, 256, 16><<<grid, RGK_TRACE_BLOCK, 0, st>>>(__VA_ARGS__); else K<false, 256, 16><<<grid, RGK_TRACE_BLOCK, 0, st>>>(__VA_ARGS__); } \
     }
 
+
+// ------------------------------------------------------------------ entry points of the camera rays
+// All camera rays through a group of RGK_ENTRY_PIX consecutive pixels of the round's list (a row of an 8x8 block, or whatever a
+// ragged tile leaves) lie in the pyramid from the eye through the group's pixel rectangle.  Descend from the root while the children that pyramid
+// can touch -- box entirely outside one of the four side planes = cannot be touched -- are few: what remains are at most
+// RGK_ENTRY_K inner nodes below which every triangle lies that any of those rays can hit.  The traversal kernel starts there
+// (all samples of the group's pixels share one descent) instead of at the root: the same triangles are tested, the top levels
+// are not walked once per ray.  Conservative by construction (boxes padded, rectangle widened); a lens camera keeps the root.
+__global__ __launch_bounds__(64) void k_entry_points(const DevScene sc, const DevCamera cam, const uint32_t xres, const uint32_t yres,
+                                                      const uint32_t* __restrict__ pix_xy, const uint32_t n_pixels, int* __restrict__ entries) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (n_pixels + RGK_ENTRY_PIX - 1u) / RGK_ENTRY_PIX) return;
+    int* e = entries + (size_t)g * RGK_ENTRY_K;
+    int list[RGK_ENTRY_K];
+    int cnt = 1;
+    list[0] = 0;
+    for (int k = 1; k < RGK_ENTRY_K; k++) list[k] = STACK_SENTINEL;
+    if (cam.lens_size == 0.0f) {
+        uint32_t x0 = 0xffffu, y0 = 0xffffu, x1 = 0, y1 = 0;
+        for (uint32_t j = g * RGK_ENTRY_PIX; j < min(g * RGK_ENTRY_PIX + RGK_ENTRY_PIX, n_pixels); j++) {
+            const uint32_t pix = pix_xy[j], x = pix & 0xffffu, y = pix >> 16;
+            x0 = min(x0, x); x1 = max(x1, x); y0 = min(y0, y); y1 = max(y1, y);
+        }
+        const float fx0 = ((float)x0 - 0.05f) / (float)xres, fx1 = ((float)x1 + 1.05f) / (float)xres;
+        const float fy0 = ((float)y0 - 0.05f) / (float)yres, fy1 = ((float)y1 + 1.05f) / (float)yres;
+        const f3 org = mk3(cam.origin[0], cam.origin[1], cam.origin[2]);
+        const f3 vs = mk3(cam.viewscreen[0], cam.viewscreen[1], cam.viewscreen[2]) - org;
+        const f3 vx = mk3(cam.viewscreen_x[0], cam.viewscreen_x[1], cam.viewscreen_x[2]), vy = mk3(cam.viewscreen_y[0], cam.viewscreen_y[1], cam.viewscreen_y[2]);
+        f3 c[4] = {vs + fx0 * vx + fy0 * vy, vs + fx1 * vx + fy0 * vy, vs + fx1 * vx + fy1 * vy, vs + fx0 * vx + fy1 * vy};
+        const f3 cm = c[0] + c[1] + c[2] + c[3];
+        f3 pl[4];
+        for (int k = 0; k < 4; k++) {
+            f3 n = cross3(c[k], c[(k + 1) & 3]);
+            if (dot3(n, cm) < 0.f) n = -n;
+            pl[k] = n * (1.0f / fmaxf(len3(n), 1e-30f)); // unit inward normal of side plane k (through the eye)
+        }
+        const float pad = 8.0f * sc.epsilon;
+        const QNode* __restrict__ nodes = sc.nodes;
+        for (int iter = 0; iter < 64; iter++) {
+            bool changed = false;
+            for (int li = 0; li < cnt && !changed; li++) {
+                const QNode q = nodes[list[li]];
+                int tc[4], nt = 0;
+                bool leaf = false;
+                for (int ch = 0; ch < 4; ch++) {
+                    if (q.qlo[0][ch] > q.qhi[0][ch]) continue; // unused slot
+                    const float s3[3] = {q.sx, q.sy, q.sz};
+                    float lo[3], hi[3];
+                    for (int a = 0; a < 3; a++) { lo[a] = q.p[a] + (float)q.qlo[a][ch] * s3[a] - pad - comp(org, a); hi[a] = q.p[a] + (float)q.qhi[a][ch] * s3[a] + pad - comp(org, a); }
+                    bool outside = false;
+                    for (int k = 0; k < 4 && !outside; k++) { // the box corner farthest INSIDE plane k is still outside: the whole box is
+                        const float d = (pl[k].x > 0.f ? hi[0] : lo[0]) * pl[k].x + (pl[k].y > 0.f ? hi[1] : lo[1]) * pl[k].y + (pl[k].z > 0.f ? hi[2] : lo[2]) * pl[k].z;
+                        const float ext = fabsf(hi[0]) + fabsf(lo[0]) + fabsf(hi[1]) + fabsf(lo[1]) + fabsf(hi[2]) + fabsf(lo[2]);
+                        outside = d < -1e-5f * ext; // (rounding of the dot product: a few ulps of its largest term)
+                    }
+                    if (outside) continue;
+                    tc[nt++] = q.child[ch];
+                    if (q.child[ch] < 0) leaf = true;
+                }
+                if (leaf) continue;                      // a touched child is a leaf: this node stays an entry
+                if (cnt - 1 + nt > RGK_ENTRY_K) continue; // no room to open it
+                for (int k = li; k + 1 < cnt; k++) list[k] = list[k + 1];
+                cnt--;
+                for (int k = 0; k < nt; k++) list[cnt++] = tc[k];
+                changed = true;
+            }
+            if (!changed) break;
+        }
+        // nearest first: by the distance of the node's box origin along the pyramid's axis (any order is correct)
+        float key[RGK_ENTRY_K];
+        for (int k = 0; k < cnt; k++) { const QNode q = nodes[list[k]]; key[k] = (q.p[0] + 127.f * q.sx - org.x) * cm.x + (q.p[1] + 127.f * q.sy - org.y) * cm.y + (q.p[2] + 127.f * q.sz - org.z) * cm.z; }
+        for (int a = 1; a < cnt; a++) for (int b = a; b > 0 && key[b] < key[b - 1]; b--) { const float t = key[b]; key[b] = key[b - 1]; key[b - 1] = t; const int u = list[b]; list[b] = list[b - 1]; list[b - 1] = u; }
+        for (int k = cnt; k < RGK_ENTRY_K; k++) list[k] = STACK_SENTINEL;
+    }
+    for (int k = 0; k < RGK_ENTRY_K; k++) e[k] = list[k];
+}
+void rgk_launch_entry_points(hipStream_t st, const DevScene& sc, const DevCamera& cam, uint32_t xres, uint32_t yres, const uint32_t* pix_xy, uint32_t n_pixels, int* entries) {
+    const uint32_t groups = (n_pixels + RGK_ENTRY_PIX - 1u) / RGK_ENTRY_PIX;
+    k_entry_points<<<(groups + 63u) / 64u, 64, 0, st>>>(sc, cam, xres, yres, pix_xy, n_pixels, entries);
+}
+
 __global__ void k_stage_mark(uint32_t* host_word, uint32_t v) { *(volatile uint32_t*)host_word = v; __threadfence_system(); }
 void rgk_launch_stage_mark(hipStream_t st, uint32_t* host_word, uint32_t v) { k_stage_mark<<<1, 1, 0, st>>>(host_word, v); }
 void rgk_launch_init_counters(hipStream_t st, uint32_t* counters, uint32_t n0) { k_init_counters<<<1, 256, 0, st>>>(counters, n0); }

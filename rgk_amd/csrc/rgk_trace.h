@@ -56,8 +56,9 @@ __device__ __forceinline__ void camera_ray(const DevCamera& cam, int x, int y, i
 // the slot, pixel jitter = 2-D dimension 0, lens = 2-D dimension 1.  A few dozen instructions and two cached table reads, so
 // the bounce-0 traversal and the bounce-0 shading each derive it from the slot number instead of one kernel writing 32 bytes
 // per path for the other two to read back (k_raygen was 4 % of a Sponza round, all of it HBM traffic).
-__device__ __forceinline__ void camera_ray_of_slot(const DevCamera& cam, const PassParams& pp, uint32_t slot, f3& o, f3& d) {
+__device__ __forceinline__ void camera_ray_of_slot(const DevCamera& cam, const PassParams& pp, uint32_t slot, f3& o, f3& d, uint32_t* j_out = nullptr) {
     uint32_t srel, j; slot_decode(pp, slot, j, srel);
+    if (j_out) *j_out = pp.j0 + j;
     const uint32_t pix = pp.pix_xy[pp.j0 + j], seed = pp.pix_seed[pp.j0 + j];
     const uint32_t s = pp.s0 + srel;
     const SamplerTab tb = {pp.htab, pp.multisample};
@@ -156,6 +157,8 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
     float tlo = 0.f, thi = 0.f, best_t = 0.f, best_a = 0.f, best_b = 0.f;
     int best_tri = -1, cur = STACK_SENTINEL, sp = 0;
 
+#define RGK_PUT(x) { if (LDSN >= STACK || sp < LDSN) stack[sp * stride] = (x); else ovf[(size_t)(sp - LDSN) * ostride] = (x); }
+#define RGK_POP() ((LDSN >= STACK || sp < LDSN) ? stack[sp * stride] : ovf[(size_t)(sp - LDSN) * ostride])
     for (;;) {
         // ------------------------------------------------ refill idle lanes
         unsigned long long act = __ballot(active);
@@ -177,8 +180,9 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
                 if (!active && rank < avail) {
                     idx = w_next + rank;
                     float tn = 0.0f, tf = 10000.0f; // Ray::near / Ray::far defaults, src/ray.hpp:25-26
+                    uint32_t pixel_j = 0;
                     if (RAYGEN) {
-                        camera_ray_of_slot(*cam, *pp, idx, o, d);
+                        camera_ray_of_slot(*cam, *pp, idx, o, d, &pixel_j);
                         ignore = 0xffffffffu;
                     } else {
                         const float4 a = q0[idx], b = q1[idx];
@@ -210,6 +214,14 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
                         // finite reciprocal keeps the slab test exact enough (boxes are eps-padded); results never depend on it.
                         inv = mk3(fminf(fmaxf(1.f / d.x, -1e30f), 1e30f), fminf(fmaxf(1.f / d.y, -1e30f), 1e30f), fminf(fmaxf(1.f / d.z, -1e30f), 1e30f));
                         cur = 0;
+                        if (RAYGEN && pp->entry) {
+                            // the walk starts at the entry nodes of this pixel's group (k_entry_points): the nodes below which
+                            // everything lies that ANY camera ray through the group's pixels can touch, nearest first
+                            const int* e = pp->entry + (size_t)(pixel_j >> RGK_ENTRY_SHIFT) * RGK_ENTRY_K;
+                            cur = e[0];
+#pragma unroll
+                            for (int k = RGK_ENTRY_K - 1; k >= 1; k--) { const int r = e[k]; if (r != STACK_SENTINEL) { RGK_PUT(r) sp++; } }
+                        }
                     } else cur = STACK_SENTINEL; // misses the scene box: reported below as a miss
                     active = true;
                 }
@@ -283,8 +295,6 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
                 // misses carry te = inf / ref = SENTINEL and sort to the back; push far -> near.
                 // Branch-free: always write the next free entry, advance only for a real child (the host
                 // sized STACK above the deepest push sequence the tree can produce, rgk_host.cpp QbvhBuilder).
-#define RGK_PUT(x) { if (LDSN >= STACK || sp < LDSN) stack[sp * stride] = (x); else ovf[(size_t)(sp - LDSN) * ostride] = (x); }
-#define RGK_POP() ((LDSN >= STACK || sp < LDSN) ? stack[sp * stride] : ovf[(size_t)(sp - LDSN) * ostride])
                 if (LDSN >= STACK || sp + 3 <= LDSN) { // all three possible entries fit the LDS part: one test instead of three
                     stack[sp * stride] = ref[3]; sp += (ref[3] != STACK_SENTINEL);
                     stack[sp * stride] = ref[2]; sp += (ref[2] != STACK_SENTINEL);

@@ -165,9 +165,10 @@ static bool slab(const Box& b, V3 o, V3 inv, float tmax, float& tn) {
 }
 struct Stat { double nodes = 0, tris = 0, rays = 0; };
 // mode 0: distance order; 1: octant order (slot ^ ~oct descending)
-float trace(int root, V3 o, V3 d, int mode, Stat& st, int* hit_tri) {
+float trace(int root, V3 o, V3 d, int mode, Stat& st, int* hit_tri, const std::vector<int>* entries = nullptr) {
     V3 inv{1 / d.x, 1 / d.y, 1 / d.z}; int oct = (d.x < 0) | ((d.y < 0) << 1) | ((d.z < 0) << 2);
     float best = 1e30f; int bt = -1; std::vector<int> stack{root};
+    if (entries) stack = *entries;
     while (!stack.empty()) {
         int n = stack.back(); stack.pop_back();
         if (n < 0) { const N2& lf = n2[~n]; for (int i = 0; i < lf.cnt; i++) { st.tris++; float t; if (tri_hit(T[order[lf.first + i]], o, d, t) && t < best) { best = t; bt = order[lf.first + i]; } } continue; }
@@ -205,6 +206,36 @@ int main(int argc, char** argv) {
                 V3 bd = t1 * (rr * std::cos(ph)) + t2 * (rr * std::sin(ph)) + n * std::sqrt(std::max(0.f, 1 - u1)); B.push_back({p.x, p.y, p.z, bd.x, bd.y, bd.z}); }
         }
         for (auto& r : B) trace(root, {r[0], r[1], r[2]}, {r[3], r[4], r[5]}, mode, bnc, nullptr);
+        if (cfg == 0 && getenv("PROBE_ENTRY")) {
+            // entry points: for each 2x2 block of the 480x270 ray grid (~ an 8x8 pixel block at 1080p), descend from the root while
+            // at most K children are touched by ANY ray of the block; depth reached = node visits every ray of the block saves
+            const int W = 480, H = 270; const int K = atoi(getenv("PROBE_ENTRY"));
+            double blocks = 0, entries = 0; Stat est;
+            for (int by = 0; by + 1 < H; by += 2) for (int bx = 0; bx + 1 < W; bx += 2) {
+                int idx[4] = {by * W + bx, by * W + bx + 1, (by + 1) * W + bx, (by + 1) * W + bx + 1};
+                std::vector<std::pair<int, int>> list{{root, 0}}; // (node, depth)
+                for (;;) {
+                    // expand the first inner node whose expansion keeps the list within K
+                    bool done = true;
+                    for (size_t li = 0; li < list.size(); li++) {
+                        int n = list[li].first; if (n < 0) continue;
+                        const NW& w = wide[n]; std::vector<int> hitc;
+                        for (int sl = 0; sl < 8; sl++) { if (w.child[sl] == INT32_MIN) continue; bool any = false;
+                            for (int q = 0; q < 4 && !any; q++) { auto& r = R[idx[q]]; V3 o{r[0], r[1], r[2]}, d{r[3], r[4], r[5]}, inv{1 / d.x, 1 / d.y, 1 / d.z}; float tn; any = slab(w.box[sl], o, inv, 1e30f, tn); }
+                            if (any) hitc.push_back(w.child[sl]); }
+                        bool leafchild = false; for (int c : hitc) if (c < 0) leafchild = true;
+                        if (getenv("PROBE_NOLEAF") && leafchild) continue; // keep a node whose touched children include a leaf
+                        if ((int)(list.size() - 1 + hitc.size()) <= K) { int dpt = list[li].second; list.erase(list.begin() + li); for (int c : hitc) list.push_back({c, dpt + 1}); done = false; break; }
+                    }
+                    if (done) break;
+                }
+                std::vector<int> ent; for (auto& e : list) ent.push_back(e.first);
+                std::reverse(ent.begin(), ent.end());
+                for (int q = 0; q < 4; q++) { auto& r = R[idx[q]]; trace(root, {r[0], r[1], r[2]}, {r[3], r[4], r[5]}, 0, est, nullptr, &ent); }
+                blocks++; entries += list.size();
+            }
+            printf("entry points (K = %d): %.2f node visits per camera ray from the block's entry list (%.2f entries per block) against %.2f from the root; triangle tests %.2f against %.2f\n", K, est.nodes / est.rays, entries / blocks, cam.nodes / cam.rays, est.tris / est.rays, cam.tris / cam.rays);
+        }
         printf("width %d %s%s: wide nodes %zu | camera rays: %.2f nodes %.2f tris per ray | bounce rays: %.2f nodes %.2f tris per ray\n", width, mode ? "octant order" : "distance order", slots ? " (octant slots)" : "",
                wide.size(), cam.nodes / cam.rays, cam.tris / cam.rays, bnc.nodes / bnc.rays, bnc.tris / bnc.rays);
     }
