@@ -48,7 +48,7 @@ def short(name):
 
 def find(d, suffix):
     f = glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True)
-    return f[0] if f else None
+    return max(f, key=os.path.getmtime) if f else None  # gpurun MERGES a run's files into gpurun_out/: older runs' files stay beside the new ones
 
 
 def counters(d):
