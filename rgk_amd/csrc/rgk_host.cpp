@@ -491,6 +491,11 @@ struct rgk_scene {
     DevBuf<float2> nearfar;
     DevBuf<uint32_t> counters, pix_xy, pix_seed, tile_buf;
     DevBuf<int> entry; // RGK_ENTRY_K traversal entry nodes per group of RGK_ENTRY_PIX pixels of the round's list
+    DevBuf<int> lentry;       // the same for the first vertex's shadow rays (single-light scenes), rebuilt per pass
+    DevBuf<uint32_t> trange;  // per pixel group: nearest / farthest first hit of a block of samples (float bits)
+    DevBuf<float4> lbox;      // per pixel group: the box its light-side entry nodes are good for
+    uint64_t lentry_key = 0;  // frame (camera + tile geometry) the light-side entries were made for ...
+    size_t lentry_done = 0;   // ... and how many pixels of the round's list they cover so far
     uint64_t entry_key = 0; // camera + tile geometry they were made for
     size_t entry_n = 0;
     DevBuf<unsigned long long> stats;
@@ -513,7 +518,7 @@ struct rgk_scene {
         for (int i = 0; i < 2; i++) { rayA[i].release(); rayB[i].release(); }
         hit.release(); thr.release(); tot.release(); shA.release(); shB.release(); shC.release(); pixsum.release();
         light.release(); generic.release(); htab.release(); lstart.release(); lv.release(); term.release(); vfin.release(); vemit.release();
-        nearfar.release(); counters.release(); pix_xy.release(); pix_seed.release(); tile_buf.release(); stats.release(); entry.release();
+        nearfar.release(); counters.release(); pix_xy.release(); pix_seed.release(); tile_buf.release(); stats.release(); entry.release(); lentry.release(); trange.release(); lbox.release();
         scratch_f.release(); scratch_u.release();
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -1223,6 +1228,15 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
     pp.batch = (uint32_t)s->batch;
     pp.pix_xy = s->pix_xy.p; pp.pix_seed = s->pix_seed.p;
     pp.entry = s->entry.p; // (null when switched off; only the unidirectional bounce-0 launch reads it)
+    pp.lentry = nullptr;
+    // one point / sphere light and nothing else that emits: every first-vertex shadow ray starts there (k_entry_points_light)
+    bool light_entry = s->entry.p && R == 0 && s->dev.n_pointlights == 1 && s->dev.n_areal == 0;
+    { const char* le = std::getenv("RGK_LIGHT_ENTRY"); if (le && le[0] == '0') light_entry = false; }
+    if (light_entry) {
+        const size_t groups = ((size_t)P + RGK_ENTRY_PIX - 1) / RGK_ENTRY_PIX + 1;
+        if ((rc = s->lentry.alloc(groups * RGK_ENTRY_K)) || (rc = s->trange.alloc(groups * 2)) || (rc = s->lbox.alloc(groups * 2))) return rc;
+        if (s->lentry_key != s->entry_key) { s->lentry_key = s->entry_key; s->lentry_done = 0; } // a new frame: rebuild as the passes come
+    }
     if ((rc = s->htab.alloc((size_t)192 * prm->multisample))) return rc;
     TIMED(3, rgk_launch_build_halton_table(st, s->dev, prm->multisample, s->htab.p));
     pp.htab = s->htab.p; pp.light = s->light.p; pp.generic = s->generic.p;
@@ -1275,10 +1289,21 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
                     else
                         TIMED(0, rgk_launch_trace_closest(st, s->dev, s->tcfg, count_stats, s->rayA[q].p, s->rayB[q].p, nullptr, s->hit.p,
                                                           cn + RGK_CNT_QUEUE + b, cn + RGK_CNT_FETCH_T + b, s->stats.p));
+                    if (b == 0 && light_entry) { // where the first hits of each pixel group lie -> where its shadow rays can go
+                        pp.lentry = s->lentry.p; pp.lbox = s->lbox.p;
+                        if ((size_t)pp.j0 + pp.npix > s->lentry_done) { // once per frame and pixel range: later rounds and sample ranges reuse it
+                            TIMED(3, rgk_launch_light_entry_points(st, s->dev, cam, pp, s->hit.p, (uint32_t)P, s->trange.p, s->lentry.p, s->lbox.p));
+                            s->lentry_done = (size_t)pp.j0 + pp.npix;
+                        }
+                    }
                     TIMED(2, rgk_launch_shade(st, s->dev, cam, pp, b, s->rayA[q].p, s->rayB[q].p, s->hit.p, s->thr.p, s->tot.p,
                                               s->rayA[q ^ 1].p, s->rayB[q ^ 1].p, s->shA.p, s->shB.p, s->shC.p, cn));
-                    TIMED(1, rgk_launch_trace_shadow(st, s->dev, s->tcfg, count_stats, s->shA.p, s->shB.p, s->shC.p, s->tot.p, nullptr,
-                                                     RGK_SHADOW_ADD, nullptr, cn + RGK_CNT_SHADOW + b, cn + RGK_CNT_FETCH_S + b, s->stats.p));
+                    if (b == 0 && light_entry)
+                        TIMED(1, rgk_launch_trace_shadow_first(st, s->dev, pp, s->tcfg, count_stats, s->shA.p, s->shB.p, s->shC.p, s->tot.p,
+                                                               cn + RGK_CNT_SHADOW + b, cn + RGK_CNT_FETCH_S + b, s->stats.p));
+                    else
+                        TIMED(1, rgk_launch_trace_shadow(st, s->dev, s->tcfg, count_stats, s->shA.p, s->shB.p, s->shC.p, s->tot.p, nullptr,
+                                                         RGK_SHADOW_ADD, nullptr, cn + RGK_CNT_SHADOW + b, cn + RGK_CNT_FETCH_S + b, s->stats.p));
                     if ((rc = stage_mark(stage_target + b + 1))) return rc;
                     if (track && b >= 3 && (b & 1) && b + 1 < prm->depth && (rc = queue_len(cn + RGK_CNT_QUEUE + b + 1, ub))) return rc;
                 }

@@ -51,6 +51,8 @@ struct PassParams {
     const uint32_t* pix_seed; // PathTracer::samplerSeed for that pixel (a2)
     const float* htab;        // halton_raw(hdim, s) for hdim < 192, s < multisample: htab[hdim * multisample + s]
     float4* light;            // per slot: the path's light {pos.xyz, code}, written by the first vertex of a path that goes on
+    const float4* lbox;       // ... and the box {lo, hi} per group inside which a shadow ray must END to use them
+    const int* lentry;        // first-vertex shadow rays of a single-light scene: entry nodes per pixel group (k_entry_points_light), or null
     const int* entry;         // camera rays: RGK_ENTRY_K node refs per group of RGK_ENTRY_PIX consecutive pixels of the round's list (k_entry_points), or null
     // bidirectional state (reverse > 0), null otherwise; per slot with stride `batch`
     float4* lstart;           // light_at_path_start.rgb
@@ -73,6 +75,7 @@ __device__ __forceinline__ uint32_t slot_of(const PassParams& pp, uint32_t j, ui
 }
 
 void rgk_launch_entry_points(hipStream_t st, const DevScene& sc, const DevCamera& cam, uint32_t xres, uint32_t yres, const uint32_t* pix_xy, uint32_t n_pixels, int* entries);
+void rgk_launch_light_entry_points(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, const float4* hit, uint32_t n_pixels_round, uint32_t* trange, int* entries, float4* lbox);
 void rgk_launch_stage_mark(hipStream_t st, uint32_t* host_word, uint32_t v); // progress: the device writes v to pinned host memory
 void rgk_launch_init_counters(hipStream_t st, uint32_t* counters, uint32_t n0);
 void rgk_launch_build_pixel_list(hipStream_t st, const rgk_tile* tiles, const uint32_t* tile_off, uint32_t n_tiles, uint32_t* pix_xy, uint32_t* pix_seed);
@@ -92,6 +95,8 @@ void rgk_launch_trace_closest(hipStream_t st, const DevScene& sc, const RgkTrace
 void rgk_launch_trace_shadow(hipStream_t st, const DevScene& sc, const RgkTraceCfg& tc, bool count_stats, const float4* shA, const float4* shB,
                              const float4* shC, float4* tot, uint8_t* vis_out, int mode, float* splat_rgb, const uint32_t* count_ptr,
                              uint32_t* fetch, unsigned long long* stats);
+void rgk_launch_trace_shadow_first(hipStream_t st, const DevScene& sc, const PassParams& pp, const RgkTraceCfg& tc, bool count_stats, const float4* shA, const float4* shB,
+                                   const float4* shC, float4* tot, const uint32_t* count_ptr, uint32_t* fetch, unsigned long long* stats);
 void rgk_launch_raygen_light(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, float4* rayA, float4* rayB,
                              float4* thr);
 void rgk_launch_raygen_camera(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, float4* rayA, float4* rayB,

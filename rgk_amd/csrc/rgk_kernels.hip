@@ -529,77 +529,186 @@ int rgk_trace_grid(int lds_entries) {
 // RGK_ENTRY_K inner nodes below which every triangle lies that any of those rays can hit.  The traversal kernel starts there
 // (all samples of the group's pixels share one descent) instead of at the root: the same triangles are tested, the top levels
 // are not walked once per ray.  Conservative by construction (boxes padded, rectangle widened); a lens camera keeps the root.
+// The descent both entry-point kernels share.  The region is {x : dot(pl[k], x - apex) >= off[k] for all k < np} (unit normals
+// pointing inward); a child box entirely on the outer side of one plane cannot be touched by any ray of the region.
+__device__ __forceinline__ void entry_descent(const DevScene& sc, const f3 apex, const f3* pl, const float* off, const int np, const float pad, const f3 axis, int* list_out) {
+    int list[RGK_ENTRY_K];
+    int cnt = 1;
+    list[0] = 0;
+    const QNode* __restrict__ nodes = sc.nodes;
+    for (int iter = 0; iter < 64; iter++) {
+        bool changed = false;
+        for (int li = 0; li < cnt && !changed; li++) {
+            const QNode q = nodes[list[li]];
+            int tc[4], nt = 0;
+            bool leaf = false;
+            for (int ch = 0; ch < 4; ch++) {
+                if (q.qlo[0][ch] > q.qhi[0][ch]) continue; // unused slot
+                const float s3[3] = {q.sx, q.sy, q.sz};
+                float lo[3], hi[3];
+                for (int a = 0; a < 3; a++) { lo[a] = q.p[a] + (float)q.qlo[a][ch] * s3[a] - pad - comp(apex, a); hi[a] = q.p[a] + (float)q.qhi[a][ch] * s3[a] + pad - comp(apex, a); }
+                bool outside = false;
+                for (int k = 0; k < np && !outside; k++) { // the box corner farthest INSIDE plane k is still outside: the whole box is
+                    const float d = (pl[k].x > 0.f ? hi[0] : lo[0]) * pl[k].x + (pl[k].y > 0.f ? hi[1] : lo[1]) * pl[k].y + (pl[k].z > 0.f ? hi[2] : lo[2]) * pl[k].z;
+                    const float ext = fabsf(hi[0]) + fabsf(lo[0]) + fabsf(hi[1]) + fabsf(lo[1]) + fabsf(hi[2]) + fabsf(lo[2]);
+                    outside = d < off[k] - 1e-5f * ext; // (rounding of the dot product: a few ulps of its largest term)
+                }
+                if (outside) continue;
+                tc[nt++] = q.child[ch];
+                if (q.child[ch] < 0) leaf = true;
+            }
+            if (leaf) continue;                      // a touched child is a leaf: this node stays an entry
+            if (cnt - 1 + nt > RGK_ENTRY_K) continue; // no room to open it
+            for (int k = li; k + 1 < cnt; k++) list[k] = list[k + 1];
+            cnt--;
+            for (int k = 0; k < nt; k++) list[cnt++] = tc[k];
+            changed = true;
+        }
+        if (!changed) break;
+    }
+    // nearest first: by the distance of the node's box centre along the region's axis (any order is correct)
+    float key[RGK_ENTRY_K];
+    for (int k = 0; k < cnt; k++) { const QNode q = nodes[list[k]]; key[k] = (q.p[0] + 127.f * q.sx - apex.x) * axis.x + (q.p[1] + 127.f * q.sy - apex.y) * axis.y + (q.p[2] + 127.f * q.sz - apex.z) * axis.z; }
+    for (int a = 1; a < cnt; a++) for (int b = a; b > 0 && key[b] < key[b - 1]; b--) { const float t = key[b]; key[b] = key[b - 1]; key[b - 1] = t; const int u = list[b]; list[b] = list[b - 1]; list[b - 1] = u; }
+    for (int k = 0; k < RGK_ENTRY_K; k++) list_out[k] = k < cnt ? list[k] : STACK_SENTINEL;
+}
+// pixel rectangle of a group (widened by a twentieth of a pixel) as view-screen fractions, and its four corner directions
+__device__ __forceinline__ void group_corners(const DevCamera& cam, uint32_t xres, uint32_t yres, const uint32_t* __restrict__ pix_xy, uint32_t n_pixels, uint32_t g, f3* c) {
+    uint32_t x0 = 0xffffu, y0 = 0xffffu, x1 = 0, y1 = 0;
+    for (uint32_t j = g * RGK_ENTRY_PIX; j < min(g * RGK_ENTRY_PIX + RGK_ENTRY_PIX, n_pixels); j++) {
+        const uint32_t pix = pix_xy[j], x = pix & 0xffffu, y = pix >> 16;
+        x0 = min(x0, x); x1 = max(x1, x); y0 = min(y0, y); y1 = max(y1, y);
+    }
+    const float fx0 = ((float)x0 - 0.05f) / (float)xres, fx1 = ((float)x1 + 1.05f) / (float)xres;
+    const float fy0 = ((float)y0 - 0.05f) / (float)yres, fy1 = ((float)y1 + 1.05f) / (float)yres;
+    const f3 vs = mk3(cam.viewscreen[0], cam.viewscreen[1], cam.viewscreen[2]) - mk3(cam.origin[0], cam.origin[1], cam.origin[2]);
+    const f3 vx = mk3(cam.viewscreen_x[0], cam.viewscreen_x[1], cam.viewscreen_x[2]), vy = mk3(cam.viewscreen_y[0], cam.viewscreen_y[1], cam.viewscreen_y[2]);
+    c[0] = vs + fx0 * vx + fy0 * vy; c[1] = vs + fx1 * vx + fy0 * vy; c[2] = vs + fx1 * vx + fy1 * vy; c[3] = vs + fx0 * vx + fy1 * vy;
+}
 __global__ __launch_bounds__(64) void k_entry_points(const DevScene sc, const DevCamera cam, const uint32_t xres, const uint32_t yres,
                                                       const uint32_t* __restrict__ pix_xy, const uint32_t n_pixels, int* __restrict__ entries) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= (n_pixels + RGK_ENTRY_PIX - 1u) / RGK_ENTRY_PIX) return;
     int* e = entries + (size_t)g * RGK_ENTRY_K;
-    int list[RGK_ENTRY_K];
-    int cnt = 1;
-    list[0] = 0;
-    for (int k = 1; k < RGK_ENTRY_K; k++) list[k] = STACK_SENTINEL;
-    if (cam.lens_size == 0.0f) {
-        uint32_t x0 = 0xffffu, y0 = 0xffffu, x1 = 0, y1 = 0;
-        for (uint32_t j = g * RGK_ENTRY_PIX; j < min(g * RGK_ENTRY_PIX + RGK_ENTRY_PIX, n_pixels); j++) {
-            const uint32_t pix = pix_xy[j], x = pix & 0xffffu, y = pix >> 16;
-            x0 = min(x0, x); x1 = max(x1, x); y0 = min(y0, y); y1 = max(y1, y);
-        }
-        const float fx0 = ((float)x0 - 0.05f) / (float)xres, fx1 = ((float)x1 + 1.05f) / (float)xres;
-        const float fy0 = ((float)y0 - 0.05f) / (float)yres, fy1 = ((float)y1 + 1.05f) / (float)yres;
-        const f3 org = mk3(cam.origin[0], cam.origin[1], cam.origin[2]);
-        const f3 vs = mk3(cam.viewscreen[0], cam.viewscreen[1], cam.viewscreen[2]) - org;
-        const f3 vx = mk3(cam.viewscreen_x[0], cam.viewscreen_x[1], cam.viewscreen_x[2]), vy = mk3(cam.viewscreen_y[0], cam.viewscreen_y[1], cam.viewscreen_y[2]);
-        f3 c[4] = {vs + fx0 * vx + fy0 * vy, vs + fx1 * vx + fy0 * vy, vs + fx1 * vx + fy1 * vy, vs + fx0 * vx + fy1 * vy};
-        const f3 cm = c[0] + c[1] + c[2] + c[3];
-        f3 pl[4];
-        for (int k = 0; k < 4; k++) {
-            f3 n = cross3(c[k], c[(k + 1) & 3]);
-            if (dot3(n, cm) < 0.f) n = -n;
-            pl[k] = n * (1.0f / fmaxf(len3(n), 1e-30f)); // unit inward normal of side plane k (through the eye)
-        }
-        const float pad = 8.0f * sc.epsilon;
-        const QNode* __restrict__ nodes = sc.nodes;
-        for (int iter = 0; iter < 64; iter++) {
-            bool changed = false;
-            for (int li = 0; li < cnt && !changed; li++) {
-                const QNode q = nodes[list[li]];
-                int tc[4], nt = 0;
-                bool leaf = false;
-                for (int ch = 0; ch < 4; ch++) {
-                    if (q.qlo[0][ch] > q.qhi[0][ch]) continue; // unused slot
-                    const float s3[3] = {q.sx, q.sy, q.sz};
-                    float lo[3], hi[3];
-                    for (int a = 0; a < 3; a++) { lo[a] = q.p[a] + (float)q.qlo[a][ch] * s3[a] - pad - comp(org, a); hi[a] = q.p[a] + (float)q.qhi[a][ch] * s3[a] + pad - comp(org, a); }
-                    bool outside = false;
-                    for (int k = 0; k < 4 && !outside; k++) { // the box corner farthest INSIDE plane k is still outside: the whole box is
-                        const float d = (pl[k].x > 0.f ? hi[0] : lo[0]) * pl[k].x + (pl[k].y > 0.f ? hi[1] : lo[1]) * pl[k].y + (pl[k].z > 0.f ? hi[2] : lo[2]) * pl[k].z;
-                        const float ext = fabsf(hi[0]) + fabsf(lo[0]) + fabsf(hi[1]) + fabsf(lo[1]) + fabsf(hi[2]) + fabsf(lo[2]);
-                        outside = d < -1e-5f * ext; // (rounding of the dot product: a few ulps of its largest term)
-                    }
-                    if (outside) continue;
-                    tc[nt++] = q.child[ch];
-                    if (q.child[ch] < 0) leaf = true;
-                }
-                if (leaf) continue;                      // a touched child is a leaf: this node stays an entry
-                if (cnt - 1 + nt > RGK_ENTRY_K) continue; // no room to open it
-                for (int k = li; k + 1 < cnt; k++) list[k] = list[k + 1];
-                cnt--;
-                for (int k = 0; k < nt; k++) list[cnt++] = tc[k];
-                changed = true;
-            }
-            if (!changed) break;
-        }
-        // nearest first: by the distance of the node's box origin along the pyramid's axis (any order is correct)
-        float key[RGK_ENTRY_K];
-        for (int k = 0; k < cnt; k++) { const QNode q = nodes[list[k]]; key[k] = (q.p[0] + 127.f * q.sx - org.x) * cm.x + (q.p[1] + 127.f * q.sy - org.y) * cm.y + (q.p[2] + 127.f * q.sz - org.z) * cm.z; }
-        for (int a = 1; a < cnt; a++) for (int b = a; b > 0 && key[b] < key[b - 1]; b--) { const float t = key[b]; key[b] = key[b - 1]; key[b - 1] = t; const int u = list[b]; list[b] = list[b - 1]; list[b - 1] = u; }
-        for (int k = cnt; k < RGK_ENTRY_K; k++) list[k] = STACK_SENTINEL;
+    if (cam.lens_size != 0.0f) { e[0] = 0; for (int k = 1; k < RGK_ENTRY_K; k++) e[k] = STACK_SENTINEL; return; }
+    f3 c[4];
+    group_corners(cam, xres, yres, pix_xy, n_pixels, g, c);
+    const f3 cm = c[0] + c[1] + c[2] + c[3];
+    f3 pl[4];
+    const float off[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < 4; k++) {
+        f3 n = cross3(c[k], c[(k + 1) & 3]);
+        if (dot3(n, cm) < 0.f) n = -n;
+        pl[k] = n * (1.0f / fmaxf(len3(n), 1e-30f)); // unit inward normal of side plane k (through the eye)
     }
+    int list[RGK_ENTRY_K];
+    entry_descent(sc, mk3(cam.origin[0], cam.origin[1], cam.origin[2]), pl, off, 4, 8.0f * sc.epsilon, cm, list);
     for (int k = 0; k < RGK_ENTRY_K; k++) e[k] = list[k];
+}
+
+// ------------------------------------------------------------------ entry points of the first vertex's shadow rays
+// A scene lit by ONE point or sphere light sends every shadow ray FROM that light (Ray(light.pos, p.pos, 20 eps), src/ray.hpp:15-22)
+// to a first hit of the group's camera rays, and those first hits lie in the slice of the group's view pyramid between the
+// nearest and the farthest of them.  k_group_trange collects that distance range per pixel group from the hit records of a
+// pass; k_entry_points_light bounds the slice by a box, spans the pyramid from the light over that box (capped behind it) and
+// descends the tree exactly like k_entry_points.  A sphere light's start points lie within `size` of its centre: every box is
+// padded by that much.
+__global__ __launch_bounds__(256) void k_group_trange(const PassParams pp, const float4* __restrict__ hit, const uint32_t n_slots, uint32_t* __restrict__ trange) {
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < ((n_slots + 63u) & ~63u); slot += gridDim.x * blockDim.x) {
+        const bool valid = slot < n_slots;
+        uint32_t srel = 0, j = 0;
+        if (valid) slot_decode(pp, slot, j, srel);
+        const uint32_t g = valid ? (pp.j0 + j) >> RGK_ENTRY_SHIFT : 0xffffffffu;
+        float tmin = __builtin_inff(), tmax = 0.f;
+        if (valid) { const float4 h = hit[slot]; if (__float_as_int(h.w) >= 0) tmin = tmax = h.x; }
+        const uint32_t g0 = __builtin_amdgcn_readfirstlane(g);
+        if (__builtin_amdgcn_ballot_w64(g != g0) == 0ull) { // the whole wave is one group (the usual case: 8 pixels x 8 samples)
+            for (int o = 32; o > 0; o >>= 1) { tmin = fminf(tmin, __shfl_xor(tmin, o)); tmax = fmaxf(tmax, __shfl_xor(tmax, o)); }
+            if ((threadIdx.x & 63) == 0 && g0 != 0xffffffffu && tmax > 0.f) { atomicMin(&trange[2 * g0], __float_as_uint(tmin)); atomicMax(&trange[2 * g0 + 1], __float_as_uint(tmax)); }
+        } else if (valid && tmax > 0.f) { atomicMin(&trange[2 * g], __float_as_uint(tmin)); atomicMax(&trange[2 * g + 1], __float_as_uint(tmax)); }
+    }
+}
+__global__ void k_init_trange(uint32_t* trange, uint32_t groups) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < groups; i += gridDim.x * blockDim.x) { trange[2 * i] = 0x7f800000u; trange[2 * i + 1] = 0u; }
+}
+__global__ __launch_bounds__(64) void k_entry_points_light(const DevScene sc, const DevCamera cam, const uint32_t xres, const uint32_t yres,
+                                                            const uint32_t* __restrict__ pix_xy, const uint32_t n_pixels, const uint32_t g_first, const uint32_t g_count,
+                                                            const uint32_t* __restrict__ trange, int* __restrict__ entries, float4* __restrict__ lbox) {
+    const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= g_count) return;
+    const uint32_t g = g_first + gi;
+    int* e = entries + (size_t)g * RGK_ENTRY_K;
+    e[0] = 0;
+    for (int k = 1; k < RGK_ENTRY_K; k++) e[k] = STACK_SENTINEL;
+    // the box the entries below are good for; a shadow ray that ends outside it starts at the root (the range comes from the
+    // first hits of one pass of the frame's first round, widened -- later rounds jitter differently).  Fallbacks: the root, good
+    // for every ray.
+    lbox[2 * (size_t)g] = make_float4(-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), 0.f);
+    lbox[2 * (size_t)g + 1] = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.f);
+    const float tmin = __uint_as_float(trange[2 * g]), tmax = __uint_as_float(trange[2 * g + 1]);
+    if (!(tmax > 0.f) || !(tmin <= tmax) || cam.lens_size != 0.0f) return; // no first hit in this group (no shadow ray will ask), or a lens camera: the root
+    const DevPointLight L = sc.pointlights[0];
+    const f3 lp = mk3(L.pos[0], L.pos[1], L.pos[2]), eye = mk3(cam.origin[0], cam.origin[1], cam.origin[2]);
+    f3 c[4];
+    group_corners(cam, xres, yres, pix_xy, n_pixels, g, c);
+    f3 axis = c[0] + c[1] + c[2] + c[3];
+    axis = axis * (1.0f / fmaxf(len3(axis), 1e-30f));
+    // the first hits: eye + t d with |d| = 1 inside the pyramid and tmin <= t <= tmax, so their axial coordinate lies between
+    // tmin * (the smallest corner cosine) and tmax: the slice of the pyramid between those two planes, a polytope with 8 corners
+    float cmin = 1.f;
+    for (int k = 0; k < 4; k++) cmin = fminf(cmin, dot3(c[k], axis) / fmaxf(len3(c[k]), 1e-30f));
+    if (!(cmin > 0.1f)) return; // (a group spread over more than ~80 degrees: the root)
+    const float a_near = tmin * cmin * 0.98f, a_far = tmax * 1.02f; // (widened: the range is that of ONE pass of ONE round; the lists serve the frame)
+    float blo[3] = {1e30f, 1e30f, 1e30f}, bhi[3] = {-1e30f, -1e30f, -1e30f};
+    for (int k = 0; k < 4; k++) {
+        const float ca = dot3(c[k], axis);
+        const f3 vn = eye + c[k] * (a_near / ca), vf = eye + c[k] * (a_far / ca);
+        for (int a = 0; a < 3; a++) { blo[a] = fminf(blo[a], fminf(comp(vn, a), comp(vf, a))); bhi[a] = fmaxf(bhi[a], fmaxf(comp(vn, a), comp(vf, a))); }
+    }
+    const float pad = L.size + 8.0f * sc.epsilon;
+    for (int a = 0; a < 3; a++) { const float m = 1e-5f * (fabsf(blo[a]) + fabsf(bhi[a])) + pad; blo[a] -= m; bhi[a] += m; }
+    // the pyramid from the light over that box
+    const f3 ctr = mk3(0.5f * (blo[0] + bhi[0]), 0.5f * (blo[1] + bhi[1]), 0.5f * (blo[2] + bhi[2]));
+    f3 w = ctr - lp;
+    const float wl = len3(w);
+    if (!(wl > 0.f)) return;
+    w = w * (1.0f / wl);
+    const f3 t0 = fabsf(w.x) > 0.9f ? mk3(0.f, 1.f, 0.f) : mk3(1.f, 0.f, 0.f);
+    f3 u = cross3(w, t0); u = u * (1.0f / len3(u));
+    const f3 v = cross3(w, u);
+    float amin = 1e30f, amax = -1e30f, bmin = 1e30f, bmax = -1e30f, wmax = 0.f, wmin = 1e30f;
+    for (int k = 0; k < 8; k++) {
+        const f3 r = mk3((k & 1) ? bhi[0] : blo[0], (k & 2) ? bhi[1] : blo[1], (k & 4) ? bhi[2] : blo[2]) - lp;
+        const float rw = dot3(r, w);
+        wmin = fminf(wmin, rw); wmax = fmaxf(wmax, rw);
+        if (rw > 0.f) { const float ra = dot3(r, u) / rw, rb = dot3(r, v) / rw; amin = fminf(amin, ra); amax = fmaxf(amax, ra); bmin = fminf(bmin, rb); bmax = fmaxf(bmax, rb); }
+    }
+    if (!(wmin > 0.05f * wmax)) return; // the light sits beside or inside the box: no useful pyramid, the root
+    const float am = 1e-4f * (1.f + fabsf(amin) + fabsf(amax)), bm = 1e-4f * (1.f + fabsf(bmin) + fabsf(bmax));
+    amin -= am; amax += am; bmin -= bm; bmax += bm;
+    f3 pl[5];
+    float off[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    pl[0] = u - amin * w; pl[1] = amax * w - u; pl[2] = v - bmin * w; pl[3] = bmax * w - v;
+    for (int k = 0; k < 4; k++) pl[k] = pl[k] * (1.0f / len3(pl[k]));
+    pl[4] = -w; off[4] = -(wmax * 1.001f + pad); // behind the box: dot(x, w) <= wmax
+    int list[RGK_ENTRY_K];
+    entry_descent(sc, lp, pl, off, 5, pad, w, list);
+    for (int k = 0; k < RGK_ENTRY_K; k++) e[k] = list[k];
+    lbox[2 * (size_t)g] = make_float4(blo[0], blo[1], blo[2], 0.f);
+    lbox[2 * (size_t)g + 1] = make_float4(bhi[0], bhi[1], bhi[2], 0.f);
 }
 void rgk_launch_entry_points(hipStream_t st, const DevScene& sc, const DevCamera& cam, uint32_t xres, uint32_t yres, const uint32_t* pix_xy, uint32_t n_pixels, int* entries) {
     const uint32_t groups = (n_pixels + RGK_ENTRY_PIX - 1u) / RGK_ENTRY_PIX;
     k_entry_points<<<(groups + 63u) / 64u, 64, 0, st>>>(sc, cam, xres, yres, pix_xy, n_pixels, entries);
+}
+void rgk_launch_light_entry_points(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, const float4* hit, uint32_t n_pixels_round, uint32_t* trange, int* entries, float4* lbox) {
+    const uint32_t g_first = pp.j0 >> RGK_ENTRY_SHIFT, g_last = (pp.j0 + pp.npix + RGK_ENTRY_PIX - 1u) >> RGK_ENTRY_SHIFT, groups = g_last - g_first;
+    k_init_trange<<<(groups + 255u) / 256u, 256, 0, st>>>(trange + 2 * (size_t)g_first, groups);
+    const uint32_t n = pp.npix * pp.ns; // every slot of this pass (done once per frame and pixel range, so 16 bytes per path do not matter)
+    uint32_t blocks = (n + 255u) / 256u;
+    if (blocks > 256u * 64u) blocks = 256u * 64u;
+    k_group_trange<<<blocks, 256, 0, st>>>(pp, hit, n, trange);
+    k_entry_points_light<<<(groups + 63u) / 64u, 64, 0, st>>>(sc, cam, pp.xres, pp.yres, pp.pix_xy, n_pixels_round, g_first, groups, trange, entries, lbox);
 }
 
 __global__ void k_stage_mark(uint32_t* host_word, uint32_t v) { *(volatile uint32_t*)host_word = v; __threadfence_system(); }
@@ -628,6 +737,11 @@ void rgk_launch_trace_shadow(hipStream_t st, const DevScene& sc, const RgkTraceC
                              const float4* shC, float4* tot, uint8_t* vis_out, int mode, float* splat_rgb, const uint32_t* count_ptr,
                              uint32_t* fetch, unsigned long long* stats) {
     RGK_TRACE_DISPATCH(k_trace_shadow, g_bound_shadow, sc, shA, shB, shC, tot, vis_out, mode, splat_rgb, count_ptr, fetch, stats, tc.ovf)
+}
+
+void rgk_launch_trace_shadow_first(hipStream_t st, const DevScene& sc, const PassParams& pp, const RgkTraceCfg& tc, bool count_stats, const float4* shA, const float4* shB,
+                                   const float4* shC, float4* tot, const uint32_t* count_ptr, uint32_t* fetch, unsigned long long* stats) {
+    RGK_TRACE_DISPATCH(k_trace_shadow_first, g_bound_shadow, sc, pp, shA, shB, shC, tot, count_ptr, fetch, stats, tc.ovf)
 }
 
 void rgk_launch_shade(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t bounce, const float4* rayA,

@@ -214,6 +214,21 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
                         // finite reciprocal keeps the slab test exact enough (boxes are eps-padded); results never depend on it.
                         inv = mk3(fminf(fmaxf(1.f / d.x, -1e30f), 1e30f), fminf(fmaxf(1.f / d.y, -1e30f), 1e30f), fminf(fmaxf(1.f / d.z, -1e30f), 1e30f));
                         cur = 0;
+                        if (ANY && pp && pp->lentry) {
+                            // first-vertex shadow rays of a single-light scene start at the entry nodes of their pixel group
+                            // (k_entry_points_light); `slot` is the path slot the radiance goes to
+                            uint32_t srel, j;
+                            slot_decode(*pp, slot, j, srel);
+                            const size_t grp = (size_t)((pp->j0 + j) >> RGK_ENTRY_SHIFT);
+                            const float4 blo = pp->lbox[2 * grp], bhi = pp->lbox[2 * grp + 1];
+                            const f3 end = o + tf * d; // where the ray stops (20 eps short of the shaded point)
+                            if (end.x >= blo.x && end.x <= bhi.x && end.y >= blo.y && end.y <= bhi.y && end.z >= blo.z && end.z <= bhi.z) {
+                                const int* e = pp->lentry + grp * RGK_ENTRY_K;
+                                cur = e[0];
+#pragma unroll
+                                for (int k = RGK_ENTRY_K - 1; k >= 1; k--) { const int r = e[k]; if (r != STACK_SENTINEL) { RGK_PUT(r) sp++; } }
+                            }
+                        }
                         if (RAYGEN && pp->entry) {
                             // the walk starts at the entry nodes of this pixel's group (k_entry_points): the nodes below which
                             // everything lies that ANY camera ray through the group's pixels can touch, nearest first
@@ -421,6 +436,22 @@ __global__ __launch_bounds__(RGK_TRACE_BLOCK, (LDSN <= 16 ? RGK_TRACE_WAVES : 5)
     uint32_t n_nodes = 0, n_tris = 0;
     trace_persistent<true, COUNT, STACK, LDSN>(sc, shA, shB, shC, nullptr, nullptr, tot, vis_out, mode, splat_rgb, *count_ptr, fetch,
                                          lds_stack + threadIdx.x, ovf + (blockIdx.x * RGK_TRACE_BLOCK + threadIdx.x), gridDim.x * RGK_TRACE_BLOCK, n_nodes, n_tris);
+    if (COUNT) {
+        atomicAdd(&stats[2], (unsigned long long)n_nodes);
+        atomicAdd(&stats[3], (unsigned long long)n_tris);
+    }
+}
+
+// K5 for the first vertex of a pass in a single-light scene: the same walker, started at the pixel group's light-side entry nodes
+template <bool COUNT, int STACK, int LDSN>
+__global__ __launch_bounds__(RGK_TRACE_BLOCK, (LDSN <= 16 ? RGK_TRACE_WAVES : 5)) void k_trace_shadow_first(const DevScene sc, const PassParams pp, const float4* __restrict__ shA,
+                                                                   const float4* __restrict__ shB, const float4* __restrict__ shC,
+                                                                   float4* __restrict__ tot, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ fetch,
+                                                                   unsigned long long* __restrict__ stats, int* __restrict__ ovf) {
+    __shared__ int lds_stack[LDSN * RGK_TRACE_BLOCK];
+    uint32_t n_nodes = 0, n_tris = 0;
+    trace_persistent<true, COUNT, STACK, LDSN>(sc, shA, shB, shC, nullptr, nullptr, tot, nullptr, RGK_SHADOW_ADD, nullptr, *count_ptr, fetch,
+                                         lds_stack + threadIdx.x, ovf + (blockIdx.x * RGK_TRACE_BLOCK + threadIdx.x), gridDim.x * RGK_TRACE_BLOCK, n_nodes, n_tris, nullptr, &pp);
     if (COUNT) {
         atomicAdd(&stats[2], (unsigned long long)n_nodes);
         atomicAdd(&stats[3], (unsigned long long)n_tris);

@@ -260,6 +260,27 @@ def test_slot_order_does_not_change_the_image(rd, oracle):
             assert np.linalg.norm(base - ref) / np.linalg.norm(ref) <= 1e-3
 
 
+def test_entry_nodes_do_not_change_the_image(rd):
+    """Camera rays start at their pixel group's entry nodes and, in a single-light scene, the first vertex's shadow rays at the
+    group's light-side entry nodes (k_entry_points, k_entry_points_light): both descents must be conservative, i.e. the image
+    with them is the image without them, bit for bit -- point light (sponza proxy), sphere light (sponza4 proxy), ragged tiles."""
+    from rgk_amd.workloads import Workload
+    for name, kw in (("sponza-1080p", dict(scale=0.15, spp=16)), ("sponza4-2160p", dict(scale=0.05, spp=16)), ("sponza-1080p", dict(scale=0.0371, spp=64))):
+        wl = Workload(name, **kw)
+        g = rd.Scene(wl.builder.to_desc())
+        tiles = rd.generate_task_list(wl.xres, wl.yres)
+        imgs = []
+        for cam_entry, light_entry in (("0", "0"), ("1", "0"), ("1", "1")):
+            os.environ["RGK_ENTRY_POINTS"], os.environ["RGK_LIGHT_ENTRY"] = cam_entry, light_entry
+            try:
+                acc, cnt, k = g.render_round(wl.camera, wl.params(), tiles)
+            finally:
+                del os.environ["RGK_ENTRY_POINTS"], os.environ["RGK_LIGHT_ENTRY"]
+            imgs.append((acc, k.path_rays, k.shadow_rays))
+        for acc, pr, sr in imgs[1:]:
+            assert np.array_equal(acc, imgs[0][0]) and pr == imgs[0][1] and sr == imgs[0][2], (name, kw)
+
+
 def test_cornell_against_the_frozen_oracle_image(rd):
     """The committed expected accumulator of BASELINE configs[0] at half resolution (tests/golden/cornell_config0_half.npz,
     rendered by the oracle, generator tools/make_fixtures.py): no oracle code runs in this test."""

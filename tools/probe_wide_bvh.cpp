@@ -182,6 +182,24 @@ float trace(int root, V3 o, V3 d, int mode, Stat& st, int* hit_tri, const std::v
     }
     st.rays++; if (hit_tri) *hit_tri = bt; return best;
 }
+
+// any-hit walk of the segment a -> b (shadow ray), optionally from an entry list; counts node visits
+static bool occluded(int root, V3 a, V3 b, Stat& st, const std::vector<int>* entries = nullptr) {
+    V3 d = b - a; float len = std::sqrt(dot(d, d)); d = d * (1 / len); V3 inv{1 / d.x, 1 / d.y, 1 / d.z};
+    const float tmax = len * 0.999f;
+    std::vector<int> stack{root}; if (entries) stack = *entries;
+    st.rays++;
+    while (!stack.empty()) {
+        int n = stack.back(); stack.pop_back();
+        if (n < 0) { const N2& lf = n2[~n]; for (int i = 0; i < lf.cnt; i++) { st.tris++; float t; if (tri_hit(T[order[lf.first + i]], a, d, t) && t < tmax) return true; } continue; }
+        st.nodes++;
+        const NW& w = wide[n]; float bt = 1e30f; int bi = -1; int hits[8]; int nh = 0;
+        for (int s = 0; s < 8; s++) { if (w.child[s] == INT32_MIN) continue; float tn; if (slab(w.box[s], a, inv, tmax, tn)) { if (tn < bt) { bt = tn; bi = nh; } hits[nh++] = w.child[s]; } }
+        for (int i = 0; i < nh; i++) if (i != bi) stack.push_back(hits[i]);
+        if (bi >= 0) stack.push_back(hits[bi]);
+    }
+    return false;
+}
 int main(int argc, char** argv) {
     FILE* f = fopen(argv[1], "rb"); fseek(f, 0, SEEK_END); long sz = ftell(f); fseek(f, 0, SEEK_SET); T.resize(sz / 36); if (fread(T.data(), 36, T.size(), f) != T.size()) return 1; fclose(f);
     f = fopen(argv[2], "rb"); fseek(f, 0, SEEK_END); sz = ftell(f); fseek(f, 0, SEEK_SET); std::vector<std::array<float, 6>> R(sz / 24); if (fread(R.data(), 24, R.size(), f) != R.size()) return 1; fclose(f);
@@ -206,6 +224,29 @@ int main(int argc, char** argv) {
                 V3 bd = t1 * (rr * std::cos(ph)) + t2 * (rr * std::sin(ph)) + n * std::sqrt(std::max(0.f, 1 - u1)); B.push_back({p.x, p.y, p.z, bd.x, bd.y, bd.z}); }
         }
         for (auto& r : B) trace(root, {r[0], r[1], r[2]}, {r[3], r[4], r[5]}, mode, bnc, nullptr);
+        if (cfg == 0 && getenv("PROBE_SHADOW")) {
+            // shadow rays of a point light: all start at the light; grouped by the 2x2 block of camera rays whose hits they go to
+            V3 L; sscanf(getenv("PROBE_SHADOW"), "%f,%f,%f", &L.x, &L.y, &L.z);
+            const int W = 480, H = 270; const int K = 6; Stat s0, s1; double entries = 0, blocks = 0;
+            std::vector<V3> hp(R.size()); std::vector<char> ok(R.size(), 0); Stat dummy;
+            for (size_t i = 0; i < R.size(); i++) { auto& r = R[i]; V3 o{r[0], r[1], r[2]}, d{r[3], r[4], r[5]}; int ht; float t = trace(root, o, d, 0, dummy, &ht); if (ht >= 0) { hp[i] = o + d * (t * 0.9999f); ok[i] = 1; } }
+            for (int by = 0; by + 1 < H; by += 2) for (int bx = 0; bx + 1 < W; bx += 2) {
+                int idx[4] = {by * W + bx, by * W + bx + 1, (by + 1) * W + bx, (by + 1) * W + bx + 1};
+                std::vector<std::pair<int, int>> list{{root, 0}};
+                for (;;) { bool done = true;
+                    for (size_t li = 0; li < list.size(); li++) { int n = list[li].first; if (n < 0) continue; const NW& w = wide[n]; std::vector<int> hitc; bool leafchild = false;
+                        for (int sl = 0; sl < 8; sl++) { if (w.child[sl] == INT32_MIN) continue; bool any = false;
+                            for (int q = 0; q < 4 && !any; q++) if (ok[idx[q]]) { V3 d = hp[idx[q]] - L; float len = std::sqrt(dot(d, d)); d = d * (1 / len); V3 inv{1 / d.x, 1 / d.y, 1 / d.z}; float tn; any = slab(w.box[sl], L, inv, len, tn); }
+                            if (any) { hitc.push_back(w.child[sl]); if (w.child[sl] < 0) leafchild = true; } }
+                        if (leafchild) continue;
+                        if ((int)(list.size() - 1 + hitc.size()) <= K) { int dpt = list[li].second; list.erase(list.begin() + li); for (int c : hitc) list.push_back({c, dpt + 1}); done = false; break; } }
+                    if (done) break; }
+                std::vector<int> ent; for (auto& e : list) ent.push_back(e.first);
+                for (int q = 0; q < 4; q++) if (ok[idx[q]]) { occluded(root, L, hp[idx[q]], s0); occluded(root, L, hp[idx[q]], s1, &ent); }
+                blocks++; entries += list.size();
+            }
+            printf("shadow rays from the light to the camera hits: %.2f node visits, %.2f triangle tests per ray from the root; %.2f and %.2f from the block's entry list (%.2f entries)\n", s0.nodes / s0.rays, s0.tris / s0.rays, s1.nodes / s1.rays, s1.tris / s1.rays, entries / blocks);
+        }
         if (cfg == 0 && getenv("PROBE_ENTRY")) {
             // entry points: for each 2x2 block of the 480x270 ray grid (~ an 8x8 pixel block at 1080p), descend from the root while
             // at most K children are touched by ANY ray of the block; depth reached = node visits every ray of the block saves
