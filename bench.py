@@ -192,7 +192,7 @@ def main():
         k_trace_camera (bounce 0) + k_trace_closest (later bounces), k_shade = its first-bounce and later-bounce variants."""
         if not prof:
             return None
-        names = {"k_trace_closest": ("k_trace_camera<false", "k_trace_closest<false"), "k_trace_shadow": ("k_trace_shadow<false",),
+        names = {"k_trace_closest": ("k_trace_camera<false", "k_trace_closest<false"), "k_trace_shadow": ("k_trace_shadow<false", "k_trace_shadow_first<false"),
                  "k_shade": ("k_shade<false, true>", "k_shade<false, false>"), "raygen_resolve": ("k_resolve",)}[kernel]
         recs = [r for k, r in prof.items() if k.startswith(names)]
         if not recs:

@@ -247,6 +247,44 @@ int main(int argc, char** argv) {
             }
             printf("shadow rays from the light to the camera hits: %.2f node visits, %.2f triangle tests per ray from the root; %.2f and %.2f from the block's entry list (%.2f entries)\n", s0.nodes / s0.rays, s0.tris / s0.rays, s1.nodes / s1.rays, s1.tris / s1.rays, entries / blocks);
         }
+        if (cfg == 0 && getenv("PROBE_BOUNCE")) {
+            // bounce rays: they start inside the box of their 2x2 block's first hits and go anywhere; per direction octant the
+            // reachable region is that box extended to infinity on three sides -- descend while at most K children overlap it
+            const int W = 480, H = 270; const int K = atoi(getenv("PROBE_BOUNCE")); Stat s0, s1; double entries = 0, lists = 0;
+            std::vector<V3> hp(R.size()); std::vector<V3> hn(R.size()); std::vector<char> ok(R.size(), 0); Stat dummy;
+            for (size_t i = 0; i < R.size(); i++) { auto& r = R[i]; V3 o{r[0], r[1], r[2]}, d{r[3], r[4], r[5]}; int ht; float t = trace(root, o, d, 0, dummy, &ht);
+                if (ht >= 0) { const Tri& tr = T[ht]; V3 n = cross(tr.b - tr.a, tr.c - tr.a); n = n * (1 / std::sqrt(dot(n, n))); if (dot(n, d) > 0) n = n * -1.f; hp[i] = o + d * t + n * 1e-3f; hn[i] = n; ok[i] = 1; } }
+            std::mt19937 rg(3); std::uniform_real_distribution<float> U(0, 1);
+            for (int by = 0; by + 1 < H; by += 2) for (int bx = 0; bx + 1 < W; bx += 2) {
+                int idx[4] = {by * W + bx, by * W + bx + 1, (by + 1) * W + bx, (by + 1) * W + bx + 1};
+                Box bg; int nok = 0; for (int q = 0; q < 4; q++) if (ok[idx[q]]) { bg.add(hp[idx[q]]); nok++; }
+                if (!nok) continue;
+                std::vector<int> ent[8];
+                for (int oc = 0; oc < 8; oc++) {
+                    Box reg; reg.lo = {(oc & 1) ? -1e30f : bg.lo.x, (oc & 2) ? -1e30f : bg.lo.y, (oc & 4) ? -1e30f : bg.lo.z};
+                    reg.hi = {(oc & 1) ? bg.hi.x : 1e30f, (oc & 2) ? bg.hi.y : 1e30f, (oc & 4) ? bg.hi.z : 1e30f};
+                    std::vector<int> list{root};
+                    for (;;) { bool done = true;
+                        for (size_t li = 0; li < list.size(); li++) { int n = list[li]; if (n < 0) continue; const NW& w = wide[n]; std::vector<int> hitc; bool leafchild = false;
+                            for (int sl = 0; sl < 8; sl++) { if (w.child[sl] == INT32_MIN) continue; const Box& b = w.box[sl];
+                                bool ov = b.hi.x >= reg.lo.x && b.lo.x <= reg.hi.x && b.hi.y >= reg.lo.y && b.lo.y <= reg.hi.y && b.hi.z >= reg.lo.z && b.lo.z <= reg.hi.z;
+                                if (ov) { hitc.push_back(w.child[sl]); if (w.child[sl] < 0) leafchild = true; } }
+                            if (leafchild) continue;
+                            if ((int)(list.size() - 1 + hitc.size()) <= K) { list.erase(list.begin() + li); for (int c : hitc) list.push_back(c); done = false; break; } }
+                        if (done) break; }
+                    ent[oc] = list; entries += list.size(); lists++;
+                }
+                for (int q = 0; q < 4; q++) if (ok[idx[q]]) for (int rep = 0; rep < 2; rep++) {
+                    V3 n = hn[idx[q]]; float u1 = U(rg), u2 = U(rg); float rr = std::sqrt(u1), ph = 6.2831853f * u2;
+                    V3 a = std::fabs(n.x) > 0.9f ? V3{0, 1, 0} : V3{1, 0, 0}; V3 t1 = cross(n, a); t1 = t1 * (1 / std::sqrt(dot(t1, t1))); V3 t2 = cross(n, t1);
+                    V3 bd = t1 * (rr * std::cos(ph)) + t2 * (rr * std::sin(ph)) + n * std::sqrt(std::max(0.f, 1 - u1));
+                    int oc = (bd.x < 0) | ((bd.y < 0) << 1) | ((bd.z < 0) << 2);
+                    int h0, h1; trace(root, hp[idx[q]], bd, 0, s0, &h0); trace(root, hp[idx[q]], bd, 0, s1, &h1, &ent[oc]);
+                    if (h0 != h1) { printf("MISMATCH\n"); }
+                }
+            }
+            printf("bounce rays, octant entry lists (K = %d): %.2f node visits, %.2f triangle tests per ray from the root; %.2f and %.2f from the lists (%.2f entries per list)\n", K, s0.nodes / s0.rays, s0.tris / s0.rays, s1.nodes / s1.rays, s1.tris / s1.rays, entries / lists);
+        }
         if (cfg == 0 && getenv("PROBE_ENTRY")) {
             // entry points: for each 2x2 block of the 480x270 ray grid (~ an 8x8 pixel block at 1080p), descend from the root while
             // at most K children are touched by ANY ray of the block; depth reached = node visits every ray of the block saves
