@@ -1,10 +1,13 @@
 // Hand-written HIP kernels for gfx950 (MI355X): the wavefront path-tracing pipeline.
 //
-//   k_raygen        K1  RenderPixel ray generation      reference src/path_tracer.cpp:53-61, src/camera.cpp:32-46
-//   k_trace_closest K2  FindIntersectKdOtherThan         reference src/scene_intersect.cpp:211-327 + src/primitives.cpp:75-166
+//   k_trace_camera  K1+K2  RenderPixel ray generation + FindIntersectKdOtherThan  reference src/path_tracer.cpp:53-61, src/camera.cpp:32-46 (rgk_trace.h)
+//   k_trace_closest K2  FindIntersectKdOtherThan         reference src/scene_intersect.cpp:211-327 + src/primitives.cpp:75-166 (rgk_trace.h)
 //   k_shade         K3/K4/K6/K7  GeneratePath body + NEE + compaction  reference src/path_tracer.cpp:134-300,427-460,485-496
-//   k_trace_shadow  K5  Scene::Visibility + accumulate   reference src/scene.cpp:670-673, src/path_tracer.cpp:431,455-457
-//   k_resolve       K9  clamp / NaN scrub / AddPixel     reference src/path_tracer.cpp:502-507, src/tracer.cpp:18, src/texture.cpp:342-347
+//   k_trace_shadow[_first]  K5  Scene::Visibility + accumulate   reference src/scene.cpp:670-673, src/path_tracer.cpp:431,455-457 (rgk_trace.h)
+//   k_resolve[_tiled]  K9  clamp / NaN scrub / AddPixel  reference src/path_tracer.cpp:502-507, src/tracer.cpp:18, src/texture.cpp:342-347
+//   k_build_pixel_list, k_build_halton_table             Tracer::Render pixel order + seeds; halton_raw per round
+//   k_entry_points, k_group_trange, k_entry_points_light  where a pixel group's camera rays / first shadow rays start in the tree
+//                                                         (no reference counterpart: work shared by the rays of a group)
 //
 // Design: one path per slot, SoA-of-float4 queues so every lane moves 16 B
 // per load; persistent waves pull 64 rays at a time from a device-side counter; a

@@ -2,22 +2,21 @@
 //
 // Result semantics are the reference's kd traversal (src/scene_intersect.cpp:4-116,211-327):
 // nearest accepted hit with t in [t0 - eps, t1 + eps] where [t0, t1] is the ray's [near, far]
-// clipped to the epsilon-padded scene box (:223-232,272), first-tested wins exact ties, the
+// clipped to the epsilon-padded scene box (:223-232,272), exact ties to the higher triangle id (see the leaf loop), the
 // `ignore` triangle is skipped; the triangle test is Triangle::TestIntersection
 // (src/primitives.cpp:75-166) with its fp64 plane solve.  The accelerator is the build's own:
 // a 4-wide BVH with 8-bit quantised child boxes, one 64-byte line per node (device_types.h).
 //
-// Execution model: persistent waves with per-lane ray REFILL.  Round-1 counters showed the
-// kernel is VALU-issue bound (SQ_ACTIVE_INST_ANY ~= all SIMD cycles) at ~1/3 lane utilisation:
-// rays of one 64-ray batch finish at very different times.  So a wave keeps a cursor into its
+// Execution model: persistent waves with per-lane ray REFILL.  The kernel is bound by the VALU -- precisely by the pipe its
+// non-fp32 instructions share (0.92-0.97 of that ceiling) -- and rays of one 64-ray batch finish at very
+// different times.  So a wave keeps a cursor into its
 // chunk of the ray queue and, whenever at most RGK_REFILL_BELOW of its lanes still hold a ray, hands the idle ones fresh rays
 // (ballot + prefix popcount); a lane that drains its stack stores its hit and goes idle.
 // The first LDSN entries of the per-lane traversal stack live in LDS as [entry][lane] (bank = lane: conflict-free), the
 // deeper ones per lane in global memory: with the whole stack in LDS the kernel was LDS-bound at 5 waves per SIMD.
 //
-// Counters after the refill (profiles/r01_trace_pmc.txt): VALU issue ~100 % of SIMD cycles AND the vector L1
-// ~90 % occupied (TA busy 67 % + 32 % pending-line stalls; L1 hit rate 93 %) -- the kernel is co-limited, which is
-// why two one-sided trades lost: 128-byte nodes with full-precision planes (85 VALU per node instead of 150 thanks
+// Round-1 counters after the refill (profiles/r01_trace_pmc.txt): the vector L1 is ~90 % occupied too (TA busy 67 % + 32 %
+// pending-line stalls; L1 hit rate 93 %) -- the kernel is co-limited, which is why two one-sided trades lost: 128-byte nodes with full-precision planes (85 VALU per node instead of 150 thanks
 // to packed fma and no decode, but 7 loads per visit instead of 4: 30.1 vs 25.9 ms) and keeping the top 96..512
 // nodes in LDS (fewer L1 lookups, but a divergent LDS / global choice per visit: 23.7..24.1 vs 23.0 ms).
 #pragma once
