@@ -279,6 +279,18 @@ def test_entry_nodes_do_not_change_the_image(rd):
             imgs.append((acc, k.path_rays, k.shadow_rays))
         for acc, pr, sr in imgs[1:]:
             assert np.array_equal(acc, imgs[0][0]) and pr == imgs[0][1] and sr == imgs[0][2], (name, kw)
+        # other slot orders (a wave then mixes pixel groups: the per-lane path of k_group_trange) and passes split over pixels and samples
+        for grp, batch in (("0", None), ("6", None), ("3", 30000)):
+            os.environ["RGK_SAMPLE_GROUP"] = grp
+            if batch: os.environ["RGK_BATCH_PATHS"] = str(batch)
+            try:
+                g2 = rd.Scene(wl.builder.to_desc())     # (a fresh scene: nothing cached from the runs above)
+                acc, cnt, k = g2.render_round(wl.camera, wl.params(), tiles)
+                acc2, _, _ = g2.render_round(wl.camera, wl.params(), tiles)      # second round of the frame: cached entry nodes
+            finally:
+                del os.environ["RGK_SAMPLE_GROUP"]
+                os.environ.pop("RGK_BATCH_PATHS", None)
+            assert np.array_equal(acc, imgs[0][0]) and np.array_equal(acc2, imgs[0][0]), (name, kw, grp, batch)
 
 
 def test_cornell_against_the_frozen_oracle_image(rd):
