@@ -1294,6 +1294,15 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
                         if ((size_t)pp.j0 + pp.npix > s->lentry_done) { // once per frame and pixel range: later rounds and sample ranges reuse it
                             TIMED(3, rgk_launch_light_entry_points(st, s->dev, cam, pp, s->hit.p, (uint32_t)P, s->trange.p, s->lentry.p, s->lbox.p));
                             s->lentry_done = (size_t)pp.j0 + pp.npix;
+                            if (std::getenv("RGK_DEBUG_BVH")) { // how many pixel groups got light-side entry nodes below the root
+                                const size_t g0 = pp.j0 >> RGK_ENTRY_SHIFT, g1 = ((size_t)pp.j0 + pp.npix + RGK_ENTRY_PIX - 1) >> RGK_ENTRY_SHIFT;
+                                std::vector<int> he((g1 - g0) * RGK_ENTRY_K);
+                                HIPCHK(hipStreamSynchronize(st));
+                                HIPCHK(hipMemcpy(he.data(), s->lentry.p + g0 * RGK_ENTRY_K, he.size() * sizeof(int), hipMemcpyDeviceToHost));
+                                size_t below = 0, total_e = 0;
+                                for (size_t g = 0; g < g1 - g0; g++) { if (he[g * RGK_ENTRY_K] != 0) below++; for (int k = 0; k < RGK_ENTRY_K; k++) total_e += he[g * RGK_ENTRY_K + k] != 0x7fffffff; }
+                                std::fprintf(stderr, "[rgk] light-side entry nodes: %zu of %zu pixel groups start below the root, %.2f entries per group\n", below, g1 - g0, (double)total_e / (double)(g1 - g0));
+                            }
                         }
                     }
                     TIMED(2, rgk_launch_shade(st, s->dev, cam, pp, b, s->rayA[q].p, s->rayB[q].p, s->hit.p, s->thr.p, s->tot.p,

@@ -614,8 +614,8 @@ __global__ __launch_bounds__(64) void k_entry_points(const DevScene sc, const De
 // to a first hit of the group's camera rays, and those first hits lie in the slice of the group's view pyramid between the
 // nearest and the farthest of them.  k_group_trange collects that distance range per pixel group from the hit records of a
 // pass; k_entry_points_light bounds the slice by a box, spans the pyramid from the light over that box (capped behind it) and
-// descends the tree exactly like k_entry_points.  A sphere light's start points lie within `size` of its centre: every box is
-// padded by that much.
+// descends the tree exactly like k_entry_points.  A sphere light's start points lie within `size` of its centre: the pyramid's
+// apex moves back so that it holds the light's box as well.
 __global__ __launch_bounds__(256) void k_group_trange(const PassParams pp, const float4* __restrict__ hit, const uint32_t n_slots, uint32_t* __restrict__ trange) {
     for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < ((n_slots + 63u) & ~63u); slot += gridDim.x * blockDim.x) {
         const bool valid = slot < n_slots;
@@ -668,34 +668,45 @@ __global__ __launch_bounds__(64) void k_entry_points_light(const DevScene sc, co
         const f3 vn = eye + c[k] * (a_near / ca), vf = eye + c[k] * (a_far / ca);
         for (int a = 0; a < 3; a++) { blo[a] = fminf(blo[a], fminf(comp(vn, a), comp(vf, a))); bhi[a] = fmaxf(bhi[a], fmaxf(comp(vn, a), comp(vf, a))); }
     }
-    const float pad = L.size + 8.0f * sc.epsilon;
+    const float pad = 8.0f * sc.epsilon;
     for (int a = 0; a < 3; a++) { const float m = 1e-5f * (fabsf(blo[a]) + fabsf(bhi[a])) + pad; blo[a] -= m; bhi[a] += m; }
-    // the pyramid from the light over that box
+    // the pyramid over that box.  A point light is its apex.  A sphere light's rays start anywhere within `size` of its centre:
+    // the apex moves back along the axis to where the lines from the light's rim to the box's rim meet (behind the light when
+    // the box is the larger of the two, far behind -- an almost parallel shaft -- when it is not), and the side planes are
+    // taken over the corners of BOTH boxes, so the region contains every segment between them.
     const f3 ctr = mk3(0.5f * (blo[0] + bhi[0]), 0.5f * (blo[1] + bhi[1]), 0.5f * (blo[2] + bhi[2]));
     f3 w = ctr - lp;
     const float wl = len3(w);
     if (!(wl > 0.f)) return;
     w = w * (1.0f / wl);
+    const float rl = L.size * 1.001f + (L.size > 0.f ? pad : 0.f);
+    const float hb = 0.5f * sqrtf((bhi[0] - blo[0]) * (bhi[0] - blo[0]) + (bhi[1] - blo[1]) * (bhi[1] - blo[1]) + (bhi[2] - blo[2]) * (bhi[2] - blo[2]));
+    float back = 0.f;
+    if (rl > 0.f) back = fmaxf(2.0f * rl, hb > 1.05f * rl ? wl * rl / (hb - rl) : 100.0f * wl);
+    const f3 apex = lp - w * back;
     const f3 t0 = fabsf(w.x) > 0.9f ? mk3(0.f, 1.f, 0.f) : mk3(1.f, 0.f, 0.f);
     f3 u = cross3(w, t0); u = u * (1.0f / len3(u));
     const f3 v = cross3(w, u);
     float amin = 1e30f, amax = -1e30f, bmin = 1e30f, bmax = -1e30f, wmax = 0.f, wmin = 1e30f;
-    for (int k = 0; k < 8; k++) {
-        const f3 r = mk3((k & 1) ? bhi[0] : blo[0], (k & 2) ? bhi[1] : blo[1], (k & 4) ? bhi[2] : blo[2]) - lp;
+    for (int k = 0; k < (rl > 0.f ? 16 : 8); k++) {
+        const f3 q = k < 8 ? mk3((k & 1) ? bhi[0] : blo[0], (k & 2) ? bhi[1] : blo[1], (k & 4) ? bhi[2] : blo[2])
+                           : mk3(lp.x + ((k & 1) ? rl : -rl), lp.y + ((k & 2) ? rl : -rl), lp.z + ((k & 4) ? rl : -rl));
+        const f3 r = q - apex;
         const float rw = dot3(r, w);
-        wmin = fminf(wmin, rw); wmax = fmaxf(wmax, rw);
+        wmin = fminf(wmin, rw);
+        if (k < 8) wmax = fmaxf(wmax, rw);
         if (rw > 0.f) { const float ra = dot3(r, u) / rw, rb = dot3(r, v) / rw; amin = fminf(amin, ra); amax = fmaxf(amax, ra); bmin = fminf(bmin, rb); bmax = fmaxf(bmax, rb); }
     }
-    if (!(wmin > 0.05f * wmax)) return; // the light sits beside or inside the box: no useful pyramid, the root
+    if (!(wmin > 0.02f * wmax)) return; // the light sits beside or inside the box: no useful pyramid, the root
     const float am = 1e-4f * (1.f + fabsf(amin) + fabsf(amax)), bm = 1e-4f * (1.f + fabsf(bmin) + fabsf(bmax));
     amin -= am; amax += am; bmin -= bm; bmax += bm;
     f3 pl[5];
     float off[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     pl[0] = u - amin * w; pl[1] = amax * w - u; pl[2] = v - bmin * w; pl[3] = bmax * w - v;
     for (int k = 0; k < 4; k++) pl[k] = pl[k] * (1.0f / len3(pl[k]));
-    pl[4] = -w; off[4] = -(wmax * 1.001f + pad); // behind the box: dot(x, w) <= wmax
+    pl[4] = -w; off[4] = -(wmax * 1.001f + pad); // behind the box: dot(x - apex, w) <= wmax
     int list[RGK_ENTRY_K];
-    entry_descent(sc, lp, pl, off, 5, pad, w, list);
+    entry_descent(sc, apex, pl, off, 5, pad, w, list);
     for (int k = 0; k < RGK_ENTRY_K; k++) e[k] = list[k];
     lbox[2 * (size_t)g] = make_float4(blo[0], blo[1], blo[2], 0.f);
     lbox[2 * (size_t)g + 1] = make_float4(bhi[0], bhi[1], bhi[2], 0.f);
