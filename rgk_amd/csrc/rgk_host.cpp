@@ -491,11 +491,12 @@ struct rgk_scene {
     DevBuf<float2> nearfar;
     DevBuf<uint32_t> counters, pix_xy, pix_seed, tile_buf;
     DevBuf<int> entry; // RGK_ENTRY_K traversal entry nodes per group of RGK_ENTRY_PIX pixels of the round's list
+    DevBuf<float> entry_cap;  // ... and up to which distance each list is complete (k_entry_points)
+    size_t entry_capped = 0;  // pixels of the round's list whose lists have been rebuilt with this frame's first-hit distances
     DevBuf<int> lentry;       // the same for the first vertex's shadow rays (single-light scenes), rebuilt per pass
     DevBuf<uint32_t> trange;  // per pixel group: nearest / farthest first hit of a block of samples (float bits)
     DevBuf<float4> lbox;      // per pixel group: the box its light-side entry nodes are good for
-    uint64_t lentry_key = 0;  // frame (camera + tile geometry) the light-side entries were made for ...
-    size_t lentry_done = 0;   // ... and how many pixels of the round's list they cover so far
+    size_t lentry_done = 0;   // how many pixels of the round's list the light-side entries of this frame cover so far
     uint64_t entry_key = 0; // camera + tile geometry they were made for
     size_t entry_n = 0;
     DevBuf<unsigned long long> stats;
@@ -518,7 +519,7 @@ struct rgk_scene {
         for (int i = 0; i < 2; i++) { rayA[i].release(); rayB[i].release(); }
         hit.release(); thr.release(); tot.release(); shA.release(); shB.release(); shC.release(); pixsum.release();
         light.release(); generic.release(); htab.release(); lstart.release(); lv.release(); term.release(); vfin.release(); vemit.release();
-        nearfar.release(); counters.release(); pix_xy.release(); pix_seed.release(); tile_buf.release(); stats.release(); entry.release(); lentry.release(); trange.release(); lbox.release();
+        nearfar.release(); counters.release(); pix_xy.release(); pix_seed.release(); tile_buf.release(); stats.release(); entry.release(); entry_cap.release(); lentry.release(); trange.release(); lbox.release();
         scratch_f.release(); scratch_u.release();
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -1152,13 +1153,14 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
             for (uint32_t t = 0; t < n_tiles; t++) mix(&tiles[t], 4 * sizeof(uint32_t)); // x0, x1, y0, y1 (the seed is the fifth word)
             const size_t n_entry = ((size_t)P + RGK_ENTRY_PIX - 1) / RGK_ENTRY_PIX * RGK_ENTRY_K;
             if (!(s->entry.p && s->entry_n == n_entry && s->entry_key == key)) {
-                if ((rc = s->entry.alloc(n_entry))) return rc;
+                if ((rc = s->entry.alloc(n_entry)) || (rc = s->entry_cap.alloc(n_entry / RGK_ENTRY_K + 1)) || (rc = s->trange.alloc((n_entry / RGK_ENTRY_K + 1) * 2))) return rc;
                 DevCamera cam0;
                 make_camera(camera, cam0);
-                rgk_launch_entry_points(st0, s->dev, cam0, prm->xres, prm->yres, s->pix_xy.p, (uint32_t)P, s->entry.p);
+                rgk_launch_entry_points(st0, s->dev, cam0, prm->xres, prm->yres, s->pix_xy.p, (uint32_t)P, 0u, (uint32_t)(n_entry / RGK_ENTRY_K), nullptr, s->entry.p, s->entry_cap.p);
                 s->entry_key = key; s->entry_n = n_entry;
+                s->entry_capped = 0; s->lentry_done = 0; // a new frame: capped / light-side lists are rebuilt as its first passes finish
             }
-        } else s->entry.release();
+        } else { s->entry.release(); s->entry_cap.release(); }
     }
     // no light at all: TracePath builds no light sub-path (`reverse > 0 && valid light`), same as reverse == 0
     const uint32_t R = (s->dev.total_point_power + s->dev.total_areal_power > 0.0f) ? prm->reverse : 0u;
@@ -1228,6 +1230,9 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
     pp.batch = (uint32_t)s->batch;
     pp.pix_xy = s->pix_xy.p; pp.pix_seed = s->pix_seed.p;
     pp.entry = s->entry.p; // (null when switched off; only the unidirectional bounce-0 launch reads it)
+    pp.entry_cap = s->entry_cap.p;
+    bool cap_entries = s->entry.p != nullptr && R == 0;
+    { const char* ce = std::getenv("RGK_ENTRY_CAP"); if (ce && ce[0] == '0') cap_entries = false; }
     pp.lentry = nullptr;
     // one point / sphere light and nothing else that emits: every first-vertex shadow ray starts there (k_entry_points_light)
     bool light_entry = s->entry.p && R == 0 && s->dev.n_pointlights == 1 && s->dev.n_areal == 0;
@@ -1235,7 +1240,6 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
     if (light_entry) {
         const size_t groups = ((size_t)P + RGK_ENTRY_PIX - 1) / RGK_ENTRY_PIX + 1;
         if ((rc = s->lentry.alloc(groups * RGK_ENTRY_K)) || (rc = s->trange.alloc(groups * 2)) || (rc = s->lbox.alloc(groups * 2))) return rc;
-        if (s->lentry_key != s->entry_key) { s->lentry_key = s->entry_key; s->lentry_done = 0; } // a new frame: rebuild as the passes come
     }
     if ((rc = s->htab.alloc((size_t)192 * prm->multisample))) return rc;
     TIMED(3, rgk_launch_build_halton_table(st, s->dev, prm->multisample, s->htab.p));
@@ -1289,10 +1293,22 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
                     else
                         TIMED(0, rgk_launch_trace_closest(st, s->dev, s->tcfg, count_stats, s->rayA[q].p, s->rayB[q].p, nullptr, s->hit.p,
                                                           cn + RGK_CNT_QUEUE + b, cn + RGK_CNT_FETCH_T + b, s->stats.p));
-                    if (b == 0 && light_entry) { // where the first hits of each pixel group lie -> where its shadow rays can go
+                    if (b == 0 && (cap_entries || light_entry)) {
+                        // once per frame and pixel range (later rounds and sample ranges reuse it): how far the first hits of each
+                        // pixel group lie -> camera-ray entry lists capped behind them, and where the group's shadow rays can go
+                        const bool need_cap = cap_entries && (size_t)pp.j0 + pp.npix > s->entry_capped;
+                        const bool need_light = light_entry && (size_t)pp.j0 + pp.npix > s->lentry_done;
+                        if (need_cap || need_light) TIMED(3, rgk_launch_group_trange(st, pp, s->hit.p, s->trange.p));
+                        if (need_cap) {
+                            const uint32_t g_first = pp.j0 >> RGK_ENTRY_SHIFT, g_last = (uint32_t)(((size_t)pp.j0 + pp.npix + RGK_ENTRY_PIX - 1) >> RGK_ENTRY_SHIFT);
+                            TIMED(3, rgk_launch_entry_points(st, s->dev, cam, prm->xres, prm->yres, s->pix_xy.p, (uint32_t)P, g_first, g_last - g_first, s->trange.p, s->entry.p, s->entry_cap.p));
+                            s->entry_capped = (size_t)pp.j0 + pp.npix;
+                        }
+                    }
+                    if (b == 0 && light_entry) {
                         pp.lentry = s->lentry.p; pp.lbox = s->lbox.p;
-                        if ((size_t)pp.j0 + pp.npix > s->lentry_done) { // once per frame and pixel range: later rounds and sample ranges reuse it
-                            TIMED(3, rgk_launch_light_entry_points(st, s->dev, cam, pp, s->hit.p, (uint32_t)P, s->trange.p, s->lentry.p, s->lbox.p));
+                        if ((size_t)pp.j0 + pp.npix > s->lentry_done) {
+                            TIMED(3, rgk_launch_light_entry_points(st, s->dev, cam, pp, (uint32_t)P, s->trange.p, s->lentry.p, s->lbox.p));
                             s->lentry_done = (size_t)pp.j0 + pp.npix;
                             if (std::getenv("RGK_DEBUG_BVH")) { // how many pixel groups got light-side entry nodes below the root
                                 const size_t g0 = pp.j0 >> RGK_ENTRY_SHIFT, g1 = ((size_t)pp.j0 + pp.npix + RGK_ENTRY_PIX - 1) >> RGK_ENTRY_SHIFT;

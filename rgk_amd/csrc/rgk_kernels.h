@@ -53,6 +53,7 @@ struct PassParams {
     float4* light;            // per slot: the path's light {pos.xyz, code}, written by the first vertex of a path that goes on
     const float4* lbox;       // ... and the box {lo, hi} per group inside which a shadow ray must END to use them
     const int* lentry;        // first-vertex shadow rays of a single-light scene: entry nodes per pixel group (k_entry_points_light), or null
+    const float* entry_cap;   // ... and per group the distance up to which that list is complete (+inf: all the way)
     const int* entry;         // camera rays: RGK_ENTRY_K node refs per group of RGK_ENTRY_PIX consecutive pixels of the round's list (k_entry_points), or null
     // bidirectional state (reverse > 0), null otherwise; per slot with stride `batch`
     float4* lstart;           // light_at_path_start.rgb
@@ -74,8 +75,10 @@ __device__ __forceinline__ uint32_t slot_of(const PassParams& pp, uint32_t j, ui
     return ((((srel >> pp.gshift) * pp.npix) + j) << pp.gshift) | (srel & ((1u << pp.gshift) - 1u));
 }
 
-void rgk_launch_entry_points(hipStream_t st, const DevScene& sc, const DevCamera& cam, uint32_t xres, uint32_t yres, const uint32_t* pix_xy, uint32_t n_pixels, int* entries);
-void rgk_launch_light_entry_points(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, const float4* hit, uint32_t n_pixels_round, uint32_t* trange, int* entries, float4* lbox);
+void rgk_launch_entry_points(hipStream_t st, const DevScene& sc, const DevCamera& cam, uint32_t xres, uint32_t yres, const uint32_t* pix_xy, uint32_t n_pixels,
+                             uint32_t g_first, uint32_t g_count, const uint32_t* trange, int* entries, float* cap);
+void rgk_launch_group_trange(hipStream_t st, const PassParams& pp, const float4* hit, uint32_t* trange);
+void rgk_launch_light_entry_points(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t n_pixels_round, const uint32_t* trange, int* entries, float4* lbox);
 void rgk_launch_stage_mark(hipStream_t st, uint32_t* host_word, uint32_t v); // progress: the device writes v to pinned host memory
 void rgk_launch_init_counters(hipStream_t st, uint32_t* counters, uint32_t n0);
 void rgk_launch_build_pixel_list(hipStream_t st, const rgk_tile* tiles, const uint32_t* tile_off, uint32_t n_tiles, uint32_t* pix_xy, uint32_t* pix_seed);

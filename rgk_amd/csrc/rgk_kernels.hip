@@ -588,24 +588,43 @@ __device__ __forceinline__ void group_corners(const DevCamera& cam, uint32_t xre
     const f3 vx = mk3(cam.viewscreen_x[0], cam.viewscreen_x[1], cam.viewscreen_x[2]), vy = mk3(cam.viewscreen_y[0], cam.viewscreen_y[1], cam.viewscreen_y[2]);
     c[0] = vs + fx0 * vx + fy0 * vy; c[1] = vs + fx1 * vx + fy0 * vy; c[2] = vs + fx1 * vx + fy1 * vy; c[3] = vs + fx0 * vx + fy1 * vy;
 }
+// `trange` (null in a frame's first round): the nearest / farthest first hit per group seen in a finished pass of this frame.
+// With it the pyramid is CAPPED behind the farthest one: the list then covers only what a ray can hit up to that distance
+// (`cap`), the ray is traced with its far end pulled in to the cap, and if it then finds nothing it is traced again from the
+// root -- a hit within the cap is the nearest hit, because everything left out lies beyond it.
 __global__ __launch_bounds__(64) void k_entry_points(const DevScene sc, const DevCamera cam, const uint32_t xres, const uint32_t yres,
-                                                      const uint32_t* __restrict__ pix_xy, const uint32_t n_pixels, int* __restrict__ entries) {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= (n_pixels + RGK_ENTRY_PIX - 1u) / RGK_ENTRY_PIX) return;
+                                                      const uint32_t* __restrict__ pix_xy, const uint32_t n_pixels, const uint32_t g_first, const uint32_t g_count,
+                                                      const uint32_t* __restrict__ trange, int* __restrict__ entries, float* __restrict__ cap) {
+    const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= g_count) return;
+    const uint32_t g = g_first + gi;
     int* e = entries + (size_t)g * RGK_ENTRY_K;
+    cap[g] = __builtin_inff();
     if (cam.lens_size != 0.0f) { e[0] = 0; for (int k = 1; k < RGK_ENTRY_K; k++) e[k] = STACK_SENTINEL; return; }
     f3 c[4];
     group_corners(cam, xres, yres, pix_xy, n_pixels, g, c);
     const f3 cm = c[0] + c[1] + c[2] + c[3];
-    f3 pl[4];
-    const float off[4] = {0.f, 0.f, 0.f, 0.f};
+    f3 pl[5];
+    float off[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < 4; k++) {
         f3 n = cross3(c[k], c[(k + 1) & 3]);
         if (dot3(n, cm) < 0.f) n = -n;
         pl[k] = n * (1.0f / fmaxf(len3(n), 1e-30f)); // unit inward normal of side plane k (through the eye)
     }
+    int np = 4;
+    const float pad = 8.0f * sc.epsilon;
+    if (trange) {
+        const float tmax = __uint_as_float(trange[2 * g + 1]);
+        if (tmax > 0.f && tmax < 1e30f) { // a point at distance t along a ray has axial coordinate <= t
+            const float far = tmax * 1.02f + pad;
+            pl[4] = cm * (-1.0f / fmaxf(len3(cm), 1e-30f));
+            off[4] = -(far + pad);
+            np = 5;
+            cap[g] = far;
+        }
+    }
     int list[RGK_ENTRY_K];
-    entry_descent(sc, mk3(cam.origin[0], cam.origin[1], cam.origin[2]), pl, off, 4, 8.0f * sc.epsilon, cm, list);
+    entry_descent(sc, mk3(cam.origin[0], cam.origin[1], cam.origin[2]), pl, off, np, pad, cm, list);
     for (int k = 0; k < RGK_ENTRY_K; k++) e[k] = list[k];
 }
 
@@ -711,17 +730,21 @@ __global__ __launch_bounds__(64) void k_entry_points_light(const DevScene sc, co
     lbox[2 * (size_t)g] = make_float4(blo[0], blo[1], blo[2], 0.f);
     lbox[2 * (size_t)g + 1] = make_float4(bhi[0], bhi[1], bhi[2], 0.f);
 }
-void rgk_launch_entry_points(hipStream_t st, const DevScene& sc, const DevCamera& cam, uint32_t xres, uint32_t yres, const uint32_t* pix_xy, uint32_t n_pixels, int* entries) {
-    const uint32_t groups = (n_pixels + RGK_ENTRY_PIX - 1u) / RGK_ENTRY_PIX;
-    k_entry_points<<<(groups + 63u) / 64u, 64, 0, st>>>(sc, cam, xres, yres, pix_xy, n_pixels, entries);
+void rgk_launch_entry_points(hipStream_t st, const DevScene& sc, const DevCamera& cam, uint32_t xres, uint32_t yres, const uint32_t* pix_xy, uint32_t n_pixels,
+                             uint32_t g_first, uint32_t g_count, const uint32_t* trange, int* entries, float* cap) {
+    k_entry_points<<<(g_count + 63u) / 64u, 64, 0, st>>>(sc, cam, xres, yres, pix_xy, n_pixels, g_first, g_count, trange, entries, cap);
 }
-void rgk_launch_light_entry_points(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, const float4* hit, uint32_t n_pixels_round, uint32_t* trange, int* entries, float4* lbox) {
+// nearest / farthest first hit per pixel group of a finished bounce-0 trace of this pass
+void rgk_launch_group_trange(hipStream_t st, const PassParams& pp, const float4* hit, uint32_t* trange) {
     const uint32_t g_first = pp.j0 >> RGK_ENTRY_SHIFT, g_last = (pp.j0 + pp.npix + RGK_ENTRY_PIX - 1u) >> RGK_ENTRY_SHIFT, groups = g_last - g_first;
     k_init_trange<<<(groups + 255u) / 256u, 256, 0, st>>>(trange + 2 * (size_t)g_first, groups);
     const uint32_t n = pp.npix * pp.ns; // every slot of this pass (done once per frame and pixel range, so 16 bytes per path do not matter)
     uint32_t blocks = (n + 255u) / 256u;
     if (blocks > 256u * 64u) blocks = 256u * 64u;
     k_group_trange<<<blocks, 256, 0, st>>>(pp, hit, n, trange);
+}
+void rgk_launch_light_entry_points(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t n_pixels_round, const uint32_t* trange, int* entries, float4* lbox) {
+    const uint32_t g_first = pp.j0 >> RGK_ENTRY_SHIFT, g_last = (pp.j0 + pp.npix + RGK_ENTRY_PIX - 1u) >> RGK_ENTRY_SHIFT, groups = g_last - g_first;
     k_entry_points_light<<<(groups + 63u) / 64u, 64, 0, st>>>(sc, cam, pp.xres, pp.yres, pp.pix_xy, n_pixels_round, g_first, groups, trange, entries, lbox);
 }
 

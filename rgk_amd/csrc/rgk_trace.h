@@ -230,7 +230,11 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
                         }
                         if (RAYGEN && pp->entry) {
                             // the walk starts at the entry nodes of this pixel's group (k_entry_points): the nodes below which
-                            // everything lies that ANY camera ray through the group's pixels can touch, nearest first
+                            // everything lies that ANY camera ray through the group's pixels can touch, nearest first -- up to
+                            // the group's cap distance if it has one: then the ray's far end is pulled in to the cap, and a ray
+                            // that finds nothing that way is traced again from the root (see where rays retire)
+                            const float capd = pp->entry_cap[pixel_j >> RGK_ENTRY_SHIFT];
+                            if (capd < thi) { thi = capd; ignore = 0xfffffffeu; } // (no triangle has that id: "capped, first attempt")
                             const int* e = pp->entry + (size_t)(pixel_j >> RGK_ENTRY_SHIFT) * RGK_ENTRY_K;
                             cur = e[0];
 #pragma unroll
@@ -366,6 +370,14 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
             else cur = STACK_SENTINEL;
         }
         // ------------------------------------------------ retire finished rays
+        if (RAYGEN && active && cur == STACK_SENTINEL && ignore == 0xfffffffeu && best_tri < 0) {
+            // nothing within the group's cap: this ray goes where the frame's earlier rays of its group did not -- again, from the root
+            float t0, t1;
+            (void)clip_to_scene(sc, o, d, 0.0f, 10000.0f, t0, t1);
+            thi = t1 + eps;
+            ignore = 0xffffffffu;
+            cur = 0; sp = 0;
+        }
         if (active && cur == STACK_SENTINEL) {
             if (!ANY) hit[idx] = make_float4(best_t, best_a, best_b, __int_as_float(best_tri));
             else if (vis_out) vis_out[idx] = best_tri < 0;

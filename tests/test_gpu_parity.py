@@ -261,21 +261,26 @@ def test_slot_order_does_not_change_the_image(rd, oracle):
 
 
 def test_entry_nodes_do_not_change_the_image(rd):
-    """Camera rays start at their pixel group's entry nodes and, in a single-light scene, the first vertex's shadow rays at the
-    group's light-side entry nodes (k_entry_points, k_entry_points_light): both descents must be conservative, i.e. the image
-    with them is the image without them, bit for bit -- point light (sponza proxy), sphere light (sponza4 proxy), ragged tiles."""
+    """Camera rays start at their pixel group's entry nodes (from a frame's second round on: lists capped behind the group's first
+    hits, with a retry from the root for a ray that finds nothing within the cap) and, in a single-light scene, the first
+    vertex's shadow rays at the group's light-side entry nodes (k_entry_points, k_entry_points_light): all of it must be
+    conservative, i.e. the image with them is the image without them, bit for bit -- point light (sponza proxy), sphere light
+    (sponza4 proxy), ragged tiles."""
     from rgk_amd.workloads import Workload
     for name, kw in (("sponza-1080p", dict(scale=0.15, spp=16)), ("sponza4-2160p", dict(scale=0.05, spp=16)), ("sponza-1080p", dict(scale=0.0371, spp=64))):
         wl = Workload(name, **kw)
         g = rd.Scene(wl.builder.to_desc())
         tiles = rd.generate_task_list(wl.xres, wl.yres)
         imgs = []
-        for cam_entry, light_entry in (("0", "0"), ("1", "0"), ("1", "1")):
-            os.environ["RGK_ENTRY_POINTS"], os.environ["RGK_LIGHT_ENTRY"] = cam_entry, light_entry
+        for cam_entry, cap, light_entry in (("0", "0", "0"), ("1", "0", "0"), ("1", "1", "0"), ("1", "1", "1")):
+            os.environ["RGK_ENTRY_POINTS"], os.environ["RGK_ENTRY_CAP"], os.environ["RGK_LIGHT_ENTRY"] = cam_entry, cap, light_entry
             try:
-                acc, cnt, k = g.render_round(wl.camera, wl.params(), tiles)
+                gg = rd.Scene(wl.builder.to_desc())        # (a fresh scene per variant: nothing cached from the previous one)
+                acc, cnt, k = gg.render_round(wl.camera, wl.params(), tiles)
+                acc2, _, k2 = gg.render_round(wl.camera, wl.params(), tiles)   # second round of the frame: lists capped behind the first hits
             finally:
-                del os.environ["RGK_ENTRY_POINTS"], os.environ["RGK_LIGHT_ENTRY"]
+                del os.environ["RGK_ENTRY_POINTS"], os.environ["RGK_ENTRY_CAP"], os.environ["RGK_LIGHT_ENTRY"]
+            assert np.array_equal(acc, acc2) and k.path_rays == k2.path_rays and k.shadow_rays == k2.shadow_rays, (name, kw, cam_entry, cap, light_entry)
             imgs.append((acc, k.path_rays, k.shadow_rays))
         for acc, pr, sr in imgs[1:]:
             assert np.array_equal(acc, imgs[0][0]) and pr == imgs[0][1] and sr == imgs[0][2], (name, kw)

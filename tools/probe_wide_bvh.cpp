@@ -292,6 +292,8 @@ int main(int argc, char** argv) {
             double blocks = 0, entries = 0; Stat est;
             for (int by = 0; by + 1 < H; by += 2) for (int bx = 0; bx + 1 < W; bx += 2) {
                 int idx[4] = {by * W + bx, by * W + bx + 1, (by + 1) * W + bx, (by + 1) * W + bx + 1};
+                float capt = 1e30f;
+                if (getenv("PROBE_CAP")) { capt = 0; Stat dm; for (int q = 0; q < 4; q++) { auto& r = R[idx[q]]; int ht; float t = trace(root, {r[0], r[1], r[2]}, {r[3], r[4], r[5]}, 0, dm, &ht); capt = std::max(capt, ht >= 0 ? t * 1.02f : 1e30f); } }
                 std::vector<std::pair<int, int>> list{{root, 0}}; // (node, depth)
                 for (;;) {
                     // expand the first inner node whose expansion keeps the list within K
@@ -300,7 +302,7 @@ int main(int argc, char** argv) {
                         int n = list[li].first; if (n < 0) continue;
                         const NW& w = wide[n]; std::vector<int> hitc;
                         for (int sl = 0; sl < 8; sl++) { if (w.child[sl] == INT32_MIN) continue; bool any = false;
-                            for (int q = 0; q < 4 && !any; q++) { auto& r = R[idx[q]]; V3 o{r[0], r[1], r[2]}, d{r[3], r[4], r[5]}, inv{1 / d.x, 1 / d.y, 1 / d.z}; float tn; any = slab(w.box[sl], o, inv, 1e30f, tn); }
+                            for (int q = 0; q < 4 && !any; q++) { auto& r = R[idx[q]]; V3 o{r[0], r[1], r[2]}, d{r[3], r[4], r[5]}, inv{1 / d.x, 1 / d.y, 1 / d.z}; float tn; any = slab(w.box[sl], o, inv, capt, tn); }
                             if (any) hitc.push_back(w.child[sl]); }
                         bool leafchild = false; for (int c : hitc) if (c < 0) leafchild = true;
                         if (getenv("PROBE_NOLEAF") && leafchild) continue; // keep a node whose touched children include a leaf
