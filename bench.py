@@ -240,7 +240,13 @@ def main():
                                 "GBps": round(bytes_per_ray * R_l / (ms["k_trace_closest"] * 1e-3) / 1e9, 1) if ms["k_trace_closest"] > 0 else None,
                                 "bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(nodes_per_ray, 2), "tris_per_ray": round(tris_per_ray, 2),
                                 "node_bytes": info.node_bytes, "tri_bytes": info.tri_bytes,
-                                "rays_per_s_closest": round(R_l / (ms["k_trace_closest"] * 1e-3) / 1e9, 3) if ms["k_trace_closest"] > 0 else None},
+                                "rays_per_s_closest": round(R_l / (ms["k_trace_closest"] * 1e-3) / 1e9, 3) if ms["k_trace_closest"] > 0 else None,
+                                # SURVEY 8(d) per shaded vertex: 56 path state + 96 vertex attributes + 32 material + 4*12*n_maps texels
+                                # (n_maps = 2) + 3*12 bump + 4*20 LTC entries = 396 B for a textured, bump-mapped LTC material (the Sponza
+                                # kind), over the shading launches' time; vertices = closest-hit rays.  Also cache-served: coherent first
+                                # vertices share their records (physical: kernels[k_shade].hbm_bytes_per_launch)
+                                "shade_bytes_per_vertex": 396,
+                                "shade_GBps": round(396.0 * R_l / (ms["k_shade"] * 1e-3) / 1e9, 1) if ms["k_shade"] > 0 else None},
                 "kernels": kernels}
 
     metric_name = {"sponza-1080p": "Sponza 1920x1080x256spp", "cornell-1024": "Cornell box 1024x1024x256spp", "cornell-256": "Cornell box 256x256x16spp",
