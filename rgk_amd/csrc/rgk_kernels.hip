@@ -22,6 +22,10 @@
 
 #include "rgk_trace.h" // K2 / K5: persistent traversal with lane refill
 
+#ifndef RGK_SKIP_DEAD_NEE
+#define RGK_SKIP_DEAD_NEE 1
+#endif
+
 // ------------------------------------------------------------------ K1: ray generation (camera_ray, camera_ray_of_slot: rgk_trace.h)
 // (Unidirectional rounds have no ray-generation kernel: bounce 0 derives the camera ray from the slot number in the traversal
 // kernel and again in the shading kernel, and the first vertex samples the path's light and starts its sum -- see
@@ -136,8 +140,23 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, RGK_SHADE_WAVES) void k_shade(cons
                     // The vertex at n == depth is the path's last (while(n < depth__), :122): its sampled direction,
                     // transfer coefficient and roulette draw can never be observed, so they are not computed.
                     const bool last = !(n < pp.depth);
+                    // At the path's last vertex the material is needed for ONE thing, the BxDF value towards the path's light -- and
+                    // for the kinds shaded here that value is exactly 0 when the light or the viewer is below the (bumped) surface's
+                    // horizon (bxdf_value_fastkind).  Then neither texels nor tables are fetched: the vertex adds its emission, if any,
+                    // and nothing else -- the same zero the long way round gives (0 * G needs G finite: the vertex is not AT the light).
+                    bool nee_dead = false;
+                    if (RGK_SKIP_DEAD_NEE && last && !FIRST && !GENERIC) {
+                        const float4 li0 = pp.light[slot];
+                        const DLight L0 = light_from_code(sc, mk3(li0.x, li0.y, li0.z), __float_as_uint(li0.w));
+                        if (L0.type < 0) nee_dead = true;
+                        else {
+                            const f3 df = pos - L0.pos;
+                            nee_dead = dot3(df, df) > 0.f && (qrot(g2l, norm3(L0.pos - pos)).z <= 0.f || VrL.z <= 0.f);
+                        }
+                    }
                     MatPrep mp;
-                    mat_prepare(sc, mat, uv, VrL, !last, mp);
+                    if (!nee_dead) mat_prepare(sc, mat, uv, VrL, !last, mp);
+                    else { mp.fast = true; mp.lobe = false; mp.diffc = mp.colorc = mk3(0.f, 0.f, 0.f); }
                     const bool no_russian = (mat.flags & RGK_MAT_NO_RUSSIAN) != 0;
                     const f3 contribution = cum; // excludes this vertex's own coefficients, :135
                     bool inside = false;
@@ -180,7 +199,7 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, RGK_SHADE_WAVES) void k_shade(cons
                                 tot[slot] = t;
                             }
                         }
-                        if (L.type >= 0) {
+                        if (L.type >= 0 && !nee_dead) {
                             const f3 diff = pos - L.pos; // Ray(light.pos, p.pos, 20 eps), src/ray.hpp:15-22
                             const f3 sd = norm3(diff);
                             const float slen = len3(diff);
