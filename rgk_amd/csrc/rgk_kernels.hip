@@ -819,7 +819,7 @@ void rgk_launch_resolve(hipStream_t st, const PassParams& pp, const float4* tot,
     if (grid > 256 * 16) grid = 256 * 16;
     if (pp.gshift == 0) { k_resolve<<<grid, 256, 0, st>>>(pp, tot, pixsum, accum_rgb, accum_count); return; }
     const uint32_t G = 1u << pp.gshift;
-    const uint32_t PT = G <= 32 ? 64u : 2048u / G; // pixels per tile: at most ~33 KB of LDS per wave
+    const uint32_t PT = G <= 8 ? 64u : 512u / G; // pixels per tile: ~9 KB of LDS per wave (more waves per CU matter more here than full lanes in the short summing phase)
     int tiles = (int)((pp.npix + PT - 1) / PT);
     k_resolve_tiled<<<tiles > 256 * 64 ? 256 * 64 : tiles, 64, PT * (G + 1) * sizeof(float4), st>>>(pp, tot, pixsum, accum_rgb, accum_count, PT);
 }
