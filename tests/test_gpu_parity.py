@@ -298,6 +298,28 @@ def test_entry_nodes_do_not_change_the_image(rd):
             assert np.array_equal(acc, imgs[0][0]) and np.array_equal(acc2, imgs[0][0]), (name, kw, grp, batch)
 
 
+def test_per_frame_caches_follow_the_camera_and_the_tiles(rd):
+    """What a scene keeps between rounds (entry nodes of the camera rays and of the first shadow rays, their cap distances) is
+    keyed by camera + tile geometry: a scene that has rendered two rounds of one frame and is then asked for another camera, or
+    for half of the tiles, must give what a fresh scene gives."""
+    from rgk_amd.workloads import Workload
+    from rgk_amd.config import camera_from_args
+    wl = Workload("sponza-1080p", scale=0.12, spp=16)
+    tiles = rd.generate_task_list(wl.xres, wl.yres)
+    a = wl.camera.ctor
+    cam2 = camera_from_args([a["pos"][0] + 3.0, a["pos"][1] - 1.0, a["pos"][2] + 2.0], a["lookat"], a["up"], a["yview"], a["xview"], wl.xres, wl.yres, a["focus_plane"], a["lens_size"])
+    half = (capi.Tile * (len(tiles) // 2))(*tiles[1::2])
+    used = rd.Scene(wl.builder.to_desc())
+    for _ in range(2):
+        used.render_round(wl.camera, wl.params(), tiles)
+    for cam, tl in ((cam2, tiles), (wl.camera, half), (cam2, half), (wl.camera, tiles)):
+        fresh = rd.Scene(wl.builder.to_desc())
+        want, _, kw = fresh.render_round(cam, wl.params(), tl)
+        for _ in range(2):      # first round of the new frame (lists rebuilt), second (capped lists)
+            got, _, kg = used.render_round(cam, wl.params(), tl)
+            assert np.array_equal(got, want) and kg.path_rays == kw.path_rays and kg.shadow_rays == kw.shadow_rays
+
+
 def test_cornell_against_the_frozen_oracle_image(rd):
     """The committed expected accumulator of BASELINE configs[0] at half resolution (tests/golden/cornell_config0_half.npz,
     rendered by the oracle, generator tools/make_fixtures.py): no oracle code runs in this test."""
