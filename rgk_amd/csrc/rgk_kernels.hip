@@ -140,14 +140,25 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, RGK_SHADE_WAVES) void k_shade(cons
                     // The vertex at n == depth is the path's last (while(n < depth__), :122): its sampled direction,
                     // transfer coefficient and roulette draw can never be observed, so they are not computed.
                     const bool last = !(n < pp.depth);
-                    // At the path's last vertex the material is needed for ONE thing, the BxDF value towards the path's light -- and
-                    // for the kinds shaded here that value is exactly 0 when the light or the viewer is below the (bumped) surface's
-                    // horizon (bxdf_value_fastkind).  Then neither texels nor tables are fetched: the vertex adds its emission, if any,
-                    // and nothing else -- the same zero the long way round gives (0 * G needs G finite: the vertex is not AT the light).
+                    const bool no_russian = (mat.flags & RGK_MAT_NO_RUSSIAN) != 0;
+                    // `ends`: nothing follows this vertex (it is the last by depth).  Then the sampled direction and its weight can never
+                    // be observed and are not computed, and the material is needed for ONE thing, the BxDF value towards the path's
+                    // light -- which for the kinds shaded here is exactly 0 when the light or the viewer is below the (bumped)
+                    // surface's horizon (bxdf_value_fastkind).  Then neither texels nor tables are fetched: the vertex adds its
+                    // emission, if any, and nothing else -- the same zero the long way round gives (0 * G needs G finite: the
+                    // vertex is not AT the light).  (Drawing the roulette number first, so that a path it ends counts as ending
+                    // here too, is exact as well -- the draw depends on nothing computed here -- but measured slower, 57.9 vs
+                    // 55.9 ms of shading per round: the lanes that could stop early wait for their wave anyway.)
+                    const bool ends = last;
+                    float4 li; // the path's light {pos, code}: sampled by the first vertex, carried in pp.light after it
+                    if (FIRST) {
+                        f3 lpos;
+                        const uint32_t lcode = light_code(sc, sample2d_t(tb, seed, s, base2d + 2u), sample1d_t(tb, seed, s, 0u), sample2d_t(tb, seed, s, base2d), lpos);
+                        li = make_float4(lpos.x, lpos.y, lpos.z, __uint_as_float(lcode));
+                    } else li = pp.light[slot];
                     bool nee_dead = false;
-                    if (RGK_SKIP_DEAD_NEE && last && !FIRST && !GENERIC) {
-                        const float4 li0 = pp.light[slot];
-                        const DLight L0 = light_from_code(sc, mk3(li0.x, li0.y, li0.z), __float_as_uint(li0.w));
+                    if (RGK_SKIP_DEAD_NEE && ends && !GENERIC) {
+                        const DLight L0 = light_from_code(sc, mk3(li.x, li.y, li.z), __float_as_uint(li.w));
                         if (L0.type < 0) nee_dead = true;
                         else {
                             const f3 df = pos - L0.pos;
@@ -155,14 +166,13 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, RGK_SHADE_WAVES) void k_shade(cons
                         }
                     }
                     MatPrep mp;
-                    if (!nee_dead) mat_prepare(sc, mat, uv, VrL, !last, mp);
+                    if (!nee_dead) mat_prepare(sc, mat, uv, VrL, !ends, mp);
                     else { mp.fast = true; mp.lobe = false; mp.diffc = mp.colorc = mk3(0.f, 0.f, 0.f); }
-                    const bool no_russian = (mat.flags & RGK_MAT_NO_RUSSIAN) != 0;
                     const f3 contribution = cum; // excludes this vertex's own coefficients, :135
                     bool inside = false;
                     f3 dir = mk3(0.f, 0.f, 0.f);
                     uint32_t n_eff = n;
-                    if (!last) {
+                    if (!ends) {
                         // BxDF sample, path_tracer.cpp:243-250
                         const quatf l2g = qinverse(g2l);
                         float2 u = sample2d_t(tb, seed, s, base2d + 3u + (n - 1u));
@@ -178,12 +188,6 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, RGK_SHADE_WAVES) void k_shade(cons
 
                     // ---- phase 3 for this vertex: NEE to the path's light, :427-460,485-496
                     {
-                        float4 li;
-                        if (FIRST) {
-                            f3 lpos;
-                            const uint32_t lcode = light_code(sc, sample2d_t(tb, seed, s, base2d + 2u), sample1d_t(tb, seed, s, 0u), sample2d_t(tb, seed, s, base2d), lpos);
-                            li = make_float4(lpos.x, lpos.y, lpos.z, __uint_as_float(lcode));
-                        } else li = pp.light[slot];
                         li_keep = li;
                         const DLight L = light_from_code(sc, mk3(li.x, li.y, li.z), __float_as_uint(li.w));
                         f3 e_front = mk3(0.f, 0.f, 0.f);
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, RGK_SHADE_WAVES) void k_shade(cons
                         }
                     }
                     // ---- continuation, path_tracer.cpp:275-300
-                    bool go = !last && !(max3c(cum) < 0.001f);
+                    bool go = !ends && !(max3c(cum) < 0.001f);
                     if (go && !no_russian && pp.russian >= 0.0f) {
                         float r = sample1d_t(tb, seed, s, c1);
                         c1++;
