@@ -1352,8 +1352,11 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
                 for (uint32_t b = 0; b < prm->depth && ub > 0; b++) {
                     int q = b & 1;
                     rgk_launch_set_bound(ub, (uint32_t)std::min<uint64_t>((uint64_t)ub * (R + 1), 0xffffffffull));
-                    TIMED(0, rgk_launch_trace_closest(st, s->dev, s->tcfg, count_stats, s->rayA[q].p, s->rayB[q].p, nullptr, s->hit.p,
-                                                      cn + RGK_CNT_QUEUE + b, cn + RGK_CNT_FETCH_T + b, s->stats.p));
+                    if (b == 0 && pp.entry) // the camera rays are in the queue (k_shade_bdpt reads them there), but the walk remakes ray i from slot i and starts at the group's entry nodes
+                        TIMED(0, rgk_launch_trace_camera(st, s->dev, cam, pp, s->tcfg, count_stats, s->hit.p, cn + RGK_CNT_QUEUE, cn + RGK_CNT_FETCH_T, s->stats.p));
+                    else
+                        TIMED(0, rgk_launch_trace_closest(st, s->dev, s->tcfg, count_stats, s->rayA[q].p, s->rayB[q].p, nullptr, s->hit.p,
+                                                          cn + RGK_CNT_QUEUE + b, cn + RGK_CNT_FETCH_T + b, s->stats.p));
                     TIMED(2, rgk_launch_shade_bdpt(st, s->dev, cam, pp, b, s->rayA[q].p, s->rayB[q].p, s->hit.p, s->thr.p, s->tot.p,
                                                    s->rayA[q ^ 1].p, s->rayB[q ^ 1].p, s->shA.p, s->shB.p, s->shC.p, cn));
                     TIMED(1, rgk_launch_trace_shadow(st, s->dev, s->tcfg, count_stats, s->shA.p, s->shB.p, s->shC.p, s->term.p, nullptr,
