@@ -52,6 +52,64 @@ def host_cores():
     return int(cap) if cap else n
 
 
+def child_environments(n, port, base=None):
+    """The environment of each of the n ranks `python bench.py --gpus n` starts when it was not itself started by
+    torch.distributed.run: what that launcher would have set (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_*)."""
+    envs = []
+    for r in range(n):
+        e = dict(os.environ if base is None else base)
+        e.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                  "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": e.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        envs.append(e)
+    return envs
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start one child process per GPU (fresh interpreters,
+    started BEFORE this process touches the GPU; nothing is exec'ed), pass rank 0's stdout through, the other ranks' stdout to
+    stderr, and return non-zero if any rank does."""
+    import socket
+    import subprocess
+    import threading
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r, env in enumerate(child_environments(n, port)):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE, stderr=None, text=True))
+
+    def relay(p, dst):
+        for line in p.stdout:
+            dst.write(line)
+            dst.flush()
+    threads = [threading.Thread(target=relay, args=(p, sys.stdout if r == 0 else sys.stderr), daemon=True) for r, p in enumerate(procs)]
+    for t in threads:
+        t.start()
+    try:
+        while any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs):  # one rank died: the others would wait in a collective for ever
+                for q in procs:
+                    if q.poll() is None:
+                        q.terminate()
+                break
+            time.sleep(0.05)
+        rcs = [p.wait(timeout=30) for p in procs]
+    except subprocess.TimeoutExpired:
+        rcs = [p.poll() if p.poll() is not None else -9 for p in procs]
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    for t in threads:
+        t.join(timeout=5)
+    bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
+    if bad:
+        print(f"bench.py: rank(s) failed: {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,6 +125,14 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + RGK_FORCE_DEVICE=0 rehearses N ranks on one GPU")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started as plain `python bench.py --gpus N` (how the driver starts it): become the launcher -- nothing below has
+        # touched the GPU yet -- and let N fresh children be the ranks
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+    if os.environ.get("RGK_BENCH_ECHO_ENV"):  # launcher test (tests/test_host_cpu.py): what a rank was given, no GPU needed
+        print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")} | {"argv": sys.argv[1:]}))
+        raise SystemExit(int(os.environ.get("RGK_BENCH_ECHO_FAIL_RANK", "-1")) == int(os.environ.get("RANK", "0")))
+
     import numpy as np
     import torch
     from rgk_amd import capi
@@ -76,9 +142,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if world != args.gpus:  # under a launcher the launcher's rank count is the truth
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")

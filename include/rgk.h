@@ -284,6 +284,12 @@ float *rgk_accum_rgb(rgk_accum *acc);      /* DEVICE pointer, 3 * xres * yres fl
 uint32_t *rgk_accum_count(rgk_accum *acc); /* DEVICE pointer, xres * yres */
 int rgk_accum_download(const rgk_accum *acc, float *rgb, uint32_t *count); /* to host buffers (either may be NULL) */
 int rgk_accum_upload(rgk_accum *acc, const float *rgb, const uint32_t *count);
+/* dst += src (both on the same device): EXRTexture::Accumulate (src/texture.cpp:403-412).  What the root rank does with a
+ * round's reduced sum -- see rgk_accum_reduce. */
+int rgk_accum_add(rgk_accum *dst, const rgk_accum *src);
+/* A digest of what the frame is rendered from (scene, camera, parameters; the host's choice of hash, 0 = none).  rgk_accum_save
+ * stores it, rgk_accum_load refuses a file whose tag differs from the accumulator's (either side untagged: not compared). */
+int rgk_accum_set_tag(rgk_accum *acc, uint64_t tag);
 
 /* Raw-accumulator checkpoint (the reference cannot resume a frame): the accumulator with the two numbers
  * that make the next round continue the sequence -- rounds done and the running task counter `seedcount`
@@ -304,7 +310,10 @@ int rgk_comm_create(const uint8_t id[RGK_COMM_ID_BYTES], int rank, int world_siz
 void rgk_comm_destroy(rgk_comm *comm);
 /* total_ob.Accumulate(output_buffer) under total_ob_mx (src/render_driver.cpp:177-182) across GPUs: in-place sum-reduce of
  * the per-GPU DEVICE accumulators to `root` (d_accum_count may be NULL when the host derives counts analytically).
- * Collective and blocking: every rank calls it once per round. */
+ * Collective and blocking: every rank calls it once per round.  IN PLACE means: afterwards the root's buffer holds the sum
+ * over all ranks and every other rank's buffer still holds its own contribution -- so what is reduced must be ONE ROUND's
+ * accumulator (rgk_accum_clear before the round), which the root then adds to its frame total (rgk_accum_add).  Reducing a
+ * buffer that keeps growing over the rounds would count the other ranks' earlier rounds again with every reduce. */
 int rgk_accum_reduce(rgk_comm *comm, float *d_accum_rgb, uint32_t *d_accum_count, uint32_t xres, uint32_t yres, int root);
 
 /* Scene::FindIntersectKdOtherThan (src/scene_intersect.cpp:211-327) for n rays.

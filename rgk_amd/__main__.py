@@ -8,8 +8,11 @@
   -s, --scale V     output brightness scale (default: auto, the brightest channel becomes 1)
   -D, --dir DIR     output directory
   -d, --debug X Y   renders only pixel (X, Y) and prints its radiance, sample count and ray counters
+  -c, --compare     output gets a `.cmp` suffix (src/main.cpp:129-131,196: an image to put beside an earlier one)
   -v / -q           verbosity up / down (default 2)
-  --checkpoint F    raw accumulator checkpoint: resumed from F if it exists, rewritten after every round
+  --checkpoint F    raw accumulator checkpoint: resumed from F if it exists, rewritten after every round.  With -r every
+                    frame has its own (F gets the frame number as a suffix); a checkpoint written for another scene, camera
+                    or parameter set is refused
   --device N        GPU to use (default 0)
 FILE is a .json or .rtc scene config.  One process drives one GPU; several GPUs: python -m torch.distributed.run ... bench.py.
 """
@@ -31,6 +34,28 @@ def insert_file_suffix(path, suffix):
     return f"{name}.{suffix}{ext}" if ext else f"{path}.{suffix}."
 
 
+def frame_digest(sb, camera, params):
+    """64-bit digest of what a frame is rendered from: geometry, materials, textures, lights, sky, camera and the PathTracer
+    parameters.  Rides in the checkpoint header (rgk_accum_set_tag): resuming after any of them changed would silently mix
+    two different images in one accumulator."""
+    import hashlib
+    h = hashlib.blake2b(digest_size=8)
+    sb.finalize()
+    for a in (sb.V, sb.N, sb.T, sb.UV, sb.F, sb.FM):
+        if a is not None:
+            h.update(a.tobytes())
+    h.update(repr([(sorted(m.items())) for m in sb.materials]).encode())
+    for t in sb.textures:
+        h.update(repr((t["kind"], t.get("color"))).encode())
+        for key in ("data", "lut"):
+            if t.get(key) is not None:
+                h.update(t[key].tobytes())
+    h.update(repr((sb.pointlights, [list(a) for a in sb.areal], sorted((k, str(v)) for k, v in sb.sky.items()))).encode())
+    h.update(bytes(camera))  # ctypes structures: their bytes
+    h.update(bytes(params))
+    return int.from_bytes(h.digest(), "little") or 1
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="python -m rgk_amd", add_help=True, description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("file")
@@ -41,6 +66,7 @@ def main(argv=None):
     ap.add_argument("-s", "--scale", type=float, default=None)
     ap.add_argument("-D", "--dir", default="")
     ap.add_argument("-d", "--debug", nargs=2, type=int, metavar=("X", "Y"))
+    ap.add_argument("-c", "--compare", action="store_true")
     ap.add_argument("-v", action="count", default=0)
     ap.add_argument("-q", action="count", default=0)
     ap.add_argument("--checkpoint", default=None)
@@ -64,6 +90,9 @@ def main(argv=None):
     output_file = os.path.join(args.dir, cfg.output_file) if args.dir else cfg.output_file
     if args.preview:
         output_file = insert_file_suffix(output_file, "preview")
+    if args.compare:
+        output_file = insert_file_suffix(output_file, "cmp")  # main.cpp:196 (after the preview suffix, before the frame number)
+    if args.preview:
         cfg.xres //= PREVIEW_DIMENSIONS_RATIO
         cfg.yres //= PREVIEW_DIMENSIONS_RATIO
         cfg.multisample = max(1, cfg.multisample // PREVIEW_RAYS_RATIO)
@@ -108,13 +137,21 @@ def main(argv=None):
             px = acc[y, x] / max(1, int(cnt[y, x]))
             print(f"pixel ({x}, {y}): radiance {px[0]:.9g} {px[1]:.9g} {px[2]:.9g}  samples {int(cnt[y, x])}  path rays {c.path_rays}  shadow rays {c.shadow_rays}")
             return 0
-        if args.checkpoint and os.path.exists(args.checkpoint):
-            drv.load_checkpoint(args.checkpoint)
-            say(2, f"Resumed from `{args.checkpoint}`: {drv.rounds_done} rounds done.")
+        # one checkpoint per frame (a finished frame's checkpoint says "all rounds done": the next frame, seen from another
+        # camera, would render nothing on top of it), tagged with what the frame is rendered from
+        ckpt = (insert_file_suffix(args.checkpoint, format_int5(frame_no)) if args.rotate else args.checkpoint) if args.checkpoint else None
+        drv.checkpoint_tag = frame_digest(sb, camera, drv.params)
+        if ckpt and os.path.exists(ckpt):
+            try:
+                drv.load_checkpoint(ckpt)
+            except RuntimeError as e:
+                print(f"ERROR: cannot resume from `{ckpt}`: {e}")
+                return 1
+            say(2, f"Resumed from `{ckpt}`: {drv.rounds_done} rounds done.")
         say(2, f"Writing to file {out}")
         timed = cfg.render_minutes is not None
         with FrameMonitor(scene, timed, cfg.render_rounds, cfg.render_minutes or 0, cfg.xres * cfg.yres, verbosity=verbosity) as mon:
-            drv.render_frame(rounds=max(0, cfg.render_rounds - drv.rounds_done) if not timed else None, output_file=out, checkpoint=args.checkpoint)
+            drv.render_frame(rounds=max(0, cfg.render_rounds - drv.rounds_done) if not timed else None, output_file=out, checkpoint=ckpt)
             mon.rays_done = sum(c.path_rays for c in drv.counters)
     return 0
 

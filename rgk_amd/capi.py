@@ -118,7 +118,7 @@ EXPORTS = ["rgk_last_error", "rgk_device_count", "rgk_scene_create", "rgk_scene_
            "rgk_bxdf_value", "rgk_bxdf_sample", "rgk_texture_sample",
            "rgk_libm_eval", "rgk_sampler_eval", "rgk_output_normalize", "rgk_output_write_exr", "rgk_float_to_half",
            "rgk_accum_create", "rgk_accum_destroy", "rgk_accum_clear", "rgk_accum_rgb", "rgk_accum_count",
-           "rgk_accum_download", "rgk_accum_upload", "rgk_accum_save", "rgk_accum_load",
+           "rgk_accum_download", "rgk_accum_upload", "rgk_accum_add", "rgk_accum_set_tag", "rgk_accum_save", "rgk_accum_load",
            "rgk_shard_tiles", "rgk_comm_get_unique_id", "rgk_comm_create", "rgk_comm_destroy", "rgk_accum_reduce"]
 
 _p = C.POINTER
@@ -160,6 +160,8 @@ def _bind(lib):
     lib.rgk_accum_count.restype = C.c_void_p
     lib.rgk_accum_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rgk_accum_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.rgk_accum_add.argtypes = [C.c_void_p, C.c_void_p]
+    lib.rgk_accum_set_tag.argtypes = [C.c_void_p, C.c_uint64]
     lib.rgk_accum_save.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32]
     lib.rgk_accum_load.argtypes = [C.c_void_p, C.c_char_p, _p(C.c_uint32), _p(C.c_uint32)]
     lib.rgk_shard_tiles.argtypes = [_p(Tile), C.c_uint32, C.c_int, C.c_int, _p(Tile), _p(C.c_uint32)]

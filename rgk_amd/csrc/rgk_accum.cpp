@@ -2,6 +2,7 @@
 // src/texture.hpp:83-118) and its raw checkpoint.  Host code; the kernels add into it (k_resolve, splats).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -16,6 +17,7 @@ struct rgk_accum {
     int device = 0;
     float* rgb = nullptr;
     uint32_t* count = nullptr;
+    uint64_t tag = 0; // what the frame was rendered from (rgk_accum_set_tag): saved with a checkpoint, checked when one is loaded
     size_t pixels() const { return (size_t)xres * yres; }
 };
 
@@ -28,8 +30,15 @@ int hip_fail(const char* what, hipError_t e) {
 struct CkptHeader { // little-endian, 32 bytes
     char magic[8];  // "RGKACC1\0"
     uint32_t xres, yres, rounds_done, seedcount;
-    uint32_t reserved[2];
+    uint32_t tag_lo, tag_hi; // rgk_accum_set_tag of the saving run (0: untagged; these words were reserved and zero before)
 };
+// dst += src, element-wise: what the root of a reduce does with the round's sum (EXRTexture::Accumulate, src/texture.cpp:403-412)
+__global__ void k_accum_add(float* __restrict__ drgb, uint32_t* __restrict__ dcnt, const float* __restrict__ srgb, const uint32_t* __restrict__ scnt, size_t P) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < 3 * P; i += (size_t)gridDim.x * blockDim.x) {
+        drgb[i] = drgb[i] + srgb[i];
+        if (i < P) dcnt[i] += scnt[i];
+    }
+}
 } // namespace
 
 extern "C" {
@@ -70,6 +79,23 @@ int rgk_accum_clear(rgk_accum* a) {
     return e == hipSuccess ? RGK_OK : hip_fail("clear accumulator", e);
 }
 
+int rgk_accum_add(rgk_accum* dst, const rgk_accum* src) {
+    if (!dst || !src) return rgk_internal_fail(RGK_ERR_INVALID, "null argument");
+    if (dst->xres != src->xres || dst->yres != src->yres || dst->device != src->device) return rgk_internal_fail(RGK_ERR_INVALID, "accumulators differ in size or device");
+    hipError_t e = hipSetDevice(dst->device);
+    if (e != hipSuccess) return hip_fail("hipSetDevice", e);
+    const size_t P = dst->pixels();
+    k_accum_add<<<(unsigned)std::min<size_t>((3 * P + 255) / 256, 8192), 256>>>(dst->rgb, dst->count, src->rgb, src->count, P);
+    if ((e = hipGetLastError()) == hipSuccess) e = hipDeviceSynchronize();
+    return e == hipSuccess ? RGK_OK : hip_fail("add accumulators", e);
+}
+
+int rgk_accum_set_tag(rgk_accum* a, uint64_t tag) {
+    if (!a) return rgk_internal_fail(RGK_ERR_INVALID, "null argument");
+    a->tag = tag;
+    return RGK_OK;
+}
+
 float* rgk_accum_rgb(rgk_accum* a) { return a ? a->rgb : nullptr; }
 uint32_t* rgk_accum_count(rgk_accum* a) { return a ? a->count : nullptr; }
 
@@ -102,6 +128,7 @@ int rgk_accum_save(const rgk_accum* a, const char* path, uint32_t rounds_done, u
     CkptHeader h{};
     std::memcpy(h.magic, "RGKACC1", 8);
     h.xres = a->xres; h.yres = a->yres; h.rounds_done = rounds_done; h.seedcount = seedcount;
+    h.tag_lo = (uint32_t)a->tag; h.tag_hi = (uint32_t)(a->tag >> 32);
     bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(rgb.data(), sizeof(float), rgb.size(), f) == rgb.size() &&
               fwrite(cnt.data(), sizeof(uint32_t), cnt.size(), f) == cnt.size();
     ok = (fclose(f) == 0) && ok;
@@ -118,6 +145,10 @@ int rgk_accum_load(rgk_accum* a, const char* path, uint32_t* rounds_done, uint32
     std::vector<uint32_t> cnt(a->pixels());
     bool ok = fread(&h, sizeof(h), 1, f) == 1 && std::memcmp(h.magic, "RGKACC1", 8) == 0;
     if (ok && (h.xres != a->xres || h.yres != a->yres)) { fclose(f); return rgk_internal_fail(RGK_ERR_INVALID, "checkpoint resolution differs from the accumulator's"); }
+    if (ok) { // a checkpoint of another scene / camera / parameter set must not be continued (both sides tagged: compared)
+        const uint64_t ftag = (uint64_t)h.tag_lo | ((uint64_t)h.tag_hi << 32);
+        if (a->tag && ftag && a->tag != ftag) { fclose(f); return rgk_internal_fail(RGK_ERR_INVALID, "checkpoint was written for a different scene, camera or parameter set"); }
+    }
     ok = ok && fread(rgb.data(), sizeof(float), rgb.size(), f) == rgb.size() && fread(cnt.data(), sizeof(uint32_t), cnt.size(), f) == cnt.size();
     fclose(f);
     if (!ok) return rgk_internal_fail(RGK_ERR_INVALID, "not a checkpoint file, or truncated");

@@ -5,11 +5,19 @@
 //
 // Pass structure on the GPU (the light sub-path does not depend on the camera path once its
 // sampler dimensions are pinned):
-//   k_raygen_light -> [k_trace_closest -> k_shade_light -> k_trace_shadow(splat)] x reverse
-//   k_raygen<BDPT> -> [k_trace_closest -> k_shade_bdpt -> k_trace_shadow(cell) -> k_finish_vertex] x depth
-// Light vertices live per slot in pp.lv; each camera vertex issues 1 + reverse shadow rays whose
-// radiance lands in pp.term[q][slot]; k_finish_vertex then forms clamp(NEE + connections + emission)
-// * contribution in the reference's order.
+//   k_raygen_light -> [k_trace_closest -> k_list_hits -> k_shade_light -> k_trace_shadow(splat)] x reverse
+//   [k_trace_camera | k_trace_closest -> k_shade<BDPT> -> k_connect -> k_trace_shadow(add) + k_trace_shadow_jobs] x depth
+// Light vertices live per slot in pp.lv, which of them exist in pp.lvmask.  The camera path is the unidirectional pipeline
+// (rgk_kernels.hip k_shade: no ray-generation kernel, camera rays made where they are traced and shaded) -- a vertex whose
+// slot has no light vertex, and that does not emit, IS a unidirectional vertex: its NEE ray goes to the plain shadow queue.
+// The others leave a record; k_connect evaluates their connections and queues ONE entry per vertex (the vertex, its
+// contribution, one radiance per ray: the 1 + reverse shadow rays all end at the vertex and start at points the slot already
+// holds), and k_trace_shadow_jobs traces the rays one after the other and forms clamp(NEE + connections + emission) *
+// contribution in the reference's order itself (rgk_trace.h, JOB).  Round 2 shaded every camera vertex in a kernel of its own
+// that looped over the light vertices (128 VGPRs + 152 bytes of scratch, 2.5 x the time of a unidirectional vertex), queued
+// 48 bytes and a 16-byte result cell per RAY, and added the cells up in another pass (k_finish_vertex, 12 % of a round).
+// Most light rays of a light far outside the geometry miss the scene: k_list_hits compacts the indices of those that hit,
+// so the light-vertex shading runs over full waves (it had 8 % of its lanes busy).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "rgk_device.h"
@@ -68,28 +76,7 @@ __global__ __launch_bounds__(256) void k_raygen_light(const DevScene sc, const D
         rayA[slot] = make_float4(o.x, o.y, o.z, d.x);
         rayB[slot] = make_float4(d.y, d.z, __uint_as_float(0xffffffffu), __uint_as_float(slot));
         thr[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(1u << 16));
-        for (uint32_t q = 0; q < pp.reverse; q++) *lv_ptr(pp, q, 3, slot) = make_float4(0.f, 0.f, 0.f, 0.f); // no vertex yet
-    }
-}
-
-// ---- camera rays only (the light sample was cached by k_raygen_light)
-__global__ __launch_bounds__(256) void k_raygen_camera(const DevScene sc, const DevCamera cam, const PassParams pp, float4* __restrict__ rayA,
-                                                        float4* __restrict__ rayB, float4* __restrict__ thr, float4* __restrict__ tot) {
-    const uint32_t n = pp.npix * pp.ns;
-    const SamplerTab tb = {pp.htab, pp.multisample};
-    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n; slot += gridDim.x * blockDim.x) {
-        uint32_t srel, j; slot_decode(pp, slot, j, srel);
-        const uint32_t pix = pp.pix_xy[pp.j0 + j], seed = pp.pix_seed[pp.j0 + j], s = pp.s0 + srel;
-        const float2 jit = sample2d_t(tb, seed, s, 0);
-        float2 lens = make_float2(0.f, 0.f);
-        if (cam.lens_size != 0.0f) lens = sample2d_t(tb, seed, s, 1);
-        f3 o, d;
-        camera_ray(cam, (int)(pix & 0xffff), (int)(pix >> 16), (int)pp.xres, (int)pp.yres, jit, lens, o, d);
-        rayA[slot] = make_float4(o.x, o.y, o.z, d.x);
-        rayB[slot] = make_float4(d.y, d.z, __uint_as_float(0xffffffffu), __uint_as_float(slot));
-        thr[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(1u << 16));
-        tot[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
-        pp.vfin[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+        pp.lvmask[slot] = 0u; // no light vertex yet
     }
 }
 
@@ -130,6 +117,21 @@ __device__ __forceinline__ void path_step(const DevScene& sc, const SamplerTab& 
     st.go = go;
 }
 
+// Queue indices of the rays that hit something, in queue order inside a workgroup's chunk (the order only decides which lanes
+// shade which vertex): ballot + prefix popcount per wave, waves added through LDS, one atomic per workgroup.
+__global__ __launch_bounds__(RGK_SHADE_BLOCK) void k_list_hits(const float4* __restrict__ hit, const uint32_t* __restrict__ count_ptr,
+                                                                uint32_t* __restrict__ list, uint32_t* __restrict__ list_count) {
+    const uint32_t count = *count_ptr;
+    __shared__ uint32_t s_cnt[RGK_SHADE_BLOCK / 64];
+    __shared__ uint32_t s_base;
+    for (uint32_t base = blockIdx.x * RGK_SHADE_BLOCK; base < count; base += gridDim.x * RGK_SHADE_BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        const bool h = i < count && __float_as_int(hit[i].w) >= 0;
+        const uint32_t p = block_append(h, list_count, s_cnt, &s_base);
+        if (h) list[p] = i;
+    }
+}
+
 // GENERIC = false / true: as in k_shade -- the first launch shades every vertex whose materials all take the fast BxDF
 // route and lists the others (queue indices in pp.generic), the second walks that list with the full BxDF code.
 // ---- light sub-path vertex k: store it, splat it to the camera, continue (russian = -1: no roulette)
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade_light(const DevSce
                                                                      const float4* __restrict__ hit, float4* __restrict__ thr,
                                                                      float4* __restrict__ nextA, float4* __restrict__ nextB, float4* __restrict__ shA,
                                                                      float4* __restrict__ shB, float4* __restrict__ shC, uint32_t* __restrict__ counters) {
-    const uint32_t count = counters[(GENERIC ? RGK_CNT_GENERIC : RGK_CNT_QUEUE) + k];
+    const uint32_t count = counters[(GENERIC ? RGK_CNT_GENERIC : RGK_CNT_HITS) + k]; // (the fast launch walks k_list_hits's list)
     const float eps = sc.epsilon;
     const SamplerTab tb = {pp.htab, pp.multisample};
     __shared__ uint32_t s_cnt[RGK_SHADE_BLOCK / 64];
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade_light(const DevSce
     lut_lds_fill(sc);
     for (uint32_t base = blockIdx.x * RGK_SHADE_BLOCK; base < count; base += gridDim.x * RGK_SHADE_BLOCK) {
         const bool valid = base + threadIdx.x < count;
-        const uint32_t i = !valid ? 0u : (GENERIC ? pp.generic[base + threadIdx.x] : base + threadIdx.x);
+        const uint32_t i = !valid ? 0u : (GENERIC ? pp.generic[base + threadIdx.x] : pp.hitlist[base + threadIdx.x]);
         bool cont = false, splat = false, defer = false;
         float4 nA = make_float4(0, 0, 0, 0), nB = nA, sA = nA, sB = nA, sC = nA;
         if (valid) {
@@ -178,6 +180,8 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade_light(const DevSce
                     // the vertex's texture colours: every camera vertex that connects to it would fetch them again
                     *lv_ptr(pp, k, 4, slot) = make_float4(mp.diffc.x, mp.diffc.y, mp.diffc.z, 0.f);
                     *lv_ptr(pp, k, 5, slot) = make_float4(mp.colorc.x, mp.colorc.y, mp.colorc.z, 0.f);
+                    // bit k: light vertex k exists; bit 7: one of them has a material on the generic BxDF route (one vertex per slot and launch: no race)
+                    pp.lvmask[slot] |= (1u << k) | (GENERIC ? 0x80u : 0u);
                     // phase 2: connect to the camera, :377-397.  camerapos = r.origin of this sample.
                     f3 campos = mk3(cam.origin[0], cam.origin[1], cam.origin[2]);
                     if (cam.lens_size != 0.0f) {
@@ -223,153 +227,67 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade_light(const DevSce
     }
 }
 
-// ---- camera-path vertex with connections
-template <bool GENERIC>
-__global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade_bdpt(const DevScene sc, const DevCamera cam, const PassParams pp, const uint32_t bounce,
-                                                                    const float4* __restrict__ rayA, const float4* __restrict__ rayB,
-                                                                    const float4* __restrict__ hit, float4* __restrict__ thr, float4* __restrict__ tot,
-                                                                    float4* __restrict__ nextA, float4* __restrict__ nextB, float4* __restrict__ shA,
-                                                                    float4* __restrict__ shB, float4* __restrict__ shC, uint32_t* __restrict__ counters) {
-    const uint32_t count = counters[(GENERIC ? RGK_CNT_GENERIC : RGK_CNT_QUEUE) + bounce];
-    const float eps = sc.epsilon;
-    const SamplerTab tb = {pp.htab, pp.multisample};
-    __shared__ uint32_t s_cnt[RGK_SHADE_BLOCK / 64];
-    __shared__ uint32_t s_base;
+// ---- connections of a camera-path vertex (path_tracer.cpp:463-480) from the record k_shade<BDPT> left: its material towards
+// every light vertex of its slot x the light vertex's material towards it x G x the light arriving there.  One thread per
+// record; the records are rare (slots whose light sub-path hit the scene), so this kernel may be as heavy as it likes.
+// jobs / rads: the vertex queue of k_trace_shadow_jobs (rgk_trace.h JOB): jobs[t] = {p, slot}, jobs[batch + t] = {contribution, mask},
+// jobs[2 batch + t] = {emission} (when mask bit 8 is set), jobs[3 batch + t] = {where the NEE ray starts}, rads[q batch + t] =
+// radiance of ray q (q = 0 NEE, q = 1..reverse the light vertices) for the bits q of mask.  A ray whose radiance is exactly
+// zero is not traced (it could only add zero).
+__global__ __launch_bounds__(256) void k_connect(const DevScene sc, const PassParams pp, const uint32_t bounce, float4* __restrict__ jobs,
+                                                  float4* __restrict__ rads, const uint32_t* __restrict__ counters) {
+    const uint32_t count = counters[RGK_CNT_CONN + bounce];
     lut_lds_fill(sc);
-    for (uint32_t base = blockIdx.x * RGK_SHADE_BLOCK; base < count; base += gridDim.x * RGK_SHADE_BLOCK) {
-        const bool valid = base + threadIdx.x < count;
-        const uint32_t i = !valid ? 0u : (GENERIC ? pp.generic[base + threadIdx.x] : base + threadIdx.x);
-        bool cont = false, have = false, defer = false;
-        float4 nA = make_float4(0, 0, 0, 0), nB = nA;
-        Vertex v;
-        v.ok = false;
-        uint32_t slot = 0;
+    const size_t bs = pp.batch;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += gridDim.x * blockDim.x) {
+        const uint32_t i = pp.connlist[t];
+        const float4 c0 = pp.conn[i], c1 = pp.conn[bs + i], c2 = pp.conn[2 * bs + i], c3 = pp.conn[3 * bs + i], c4 = pp.conn[4 * bs + i], c5 = pp.conn[5 * bs + i];
+        const f3 pos = mk3(c0.x, c0.y, c0.z), lightN = mk3(c1.x, c1.y, c1.z), VrL = mk3(c3.x, c3.y, c3.z);
+        const uint32_t slot = __float_as_uint(c0.w), mat_id = __float_as_uint(c1.w);
+        quatf g2l; g2l.x = c2.x; g2l.y = c2.y; g2l.z = c2.z; g2l.w = c2.w;
+        const float2 uv = make_float2(c3.w, c4.w);
+        const uint32_t lvm = pp.lvmask[slot];
+        const DevMaterial mat = mat_load(sc, mat_id);
+        // the fast route needs every material involved to be a diffuse / LTC one; otherwise the full BxDF code (the same values)
+        const bool fast = mat_is_fast(mat.kind) && !(lvm & 0x80u);
         MatPrep mp;
         mp.fast = false;
-        if (valid) {
-            const float4 a = rayA[i], b = rayB[i], h = hit[i];
-            slot = __float_as_uint(b.w);
-            const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
-            const float4 st4 = thr[slot];
-            f3 cum = mk3(st4.x, st4.y, st4.z);
-            const uint32_t bits = __float_as_uint(st4.w);
-            const uint32_t n = (bits & 0xffffu) + 1u;
-            uint32_t c1 = bits >> 16;
-            if (__float_as_int(h.w) < 0) {
-                const f3 add = cum * skybox(sc, -d);
-                float4 t = tot[slot];
-                t.x = t.x + add.x; t.y = t.y + add.y; t.z = t.z + add.z;
-                tot[slot] = t;
+        if (fast) mat_prepare(sc, mat, uv, VrL, false, mp);
+        uint32_t mask = 0;
+        if (c5.x != 0.f || c5.y != 0.f || c5.z != 0.f) {
+            mask |= 1u;
+            rads[t] = make_float4(c5.x, c5.y, c5.z, 0.f);
+            jobs[3 * bs + t] = pp.light[slot]; // Ray(light.pos, p.pos): the stored position IS Light::pos
+        }
+        for (uint32_t q = 1; q <= pp.reverse; q++) {
+            if (!(lvm & (1u << (q - 1u)))) continue;
+            const float4 l0 = *lv_ptr(pp, q - 1, 0, slot), l1 = *lv_ptr(pp, q - 1, 1, slot), l2 = *lv_ptr(pp, q - 1, 2, slot), l3 = *lv_ptr(pp, q - 1, 3, slot);
+            const f3 lpos = mk3(l0.x, l0.y, l0.z), lN = mk3(l1.x, l1.y, l1.z), lVr = mk3(l2.x, l2.y, l2.z);
+            const float2 luv = make_float2(l1.w, l2.w);
+            const f3 light_to_p = norm3(pos - lpos);
+            const f3 p_to_light = -light_to_p;
+            const quatf lg2l = rotation_between(lN, mk3(0.f, 0.f, 1.f));
+            f3 f_light, f_point;
+            if (fast) {
+                f_light = bxdf_value_fastkind(sc, mat_load(sc, __float_as_uint(l0.w)), *lv_ptr(pp, q - 1, 4, slot), *lv_ptr(pp, q - 1, 5, slot), qrot(lg2l, light_to_p), qrot(lg2l, lVr));
+                f_point = mat_value_at<false>(sc, (int)mat_id, mat, mp, VrL, qrot(g2l, p_to_light), uv);
             } else {
-                surface_point(sc, pp.bumpmap_scale, o, d, h, v);
-                if (!GENERIC && v.ok) { // every material this vertex will evaluate: its own and those of the path's light vertices
-                    defer = !mat_is_fast(v.mat.kind);
-                    for (uint32_t q = 0; q < pp.reverse; q++)
-                        if (lv_ptr(pp, q, 3, slot)->w != 0.0f && !mat_is_fast(mat_load(sc, __float_as_uint(lv_ptr(pp, q, 0, slot)->w)).kind)) defer = true;
-                }
-                if (v.ok && !defer) {
-                    have = true;
-                    uint32_t srel, j; slot_decode(pp, slot, j, srel);
-                    const uint32_t seed = pp.pix_seed[pp.j0 + j], s = pp.s0 + srel;
-                    const uint32_t base2d = (cam.lens_size != 0.0f) ? 2u : 1u;
-                    mat_prepare(sc, v.mat, v.uv, v.VrL, n < pp.depth, mp);
-                    f3 e_front = mk3(0.f, 0.f, 0.f);
-                    if (dot3(v.faceN, v.Vr) > 0) e_front = mk3(v.mat.emission[0], v.mat.emission[1], v.mat.emission[2]);
-                    pp.vfin[slot] = make_float4(cum.x, cum.y, cum.z, 1.0f); // contribution of this vertex
-                    pp.vemit[slot] = make_float4(e_front.x, e_front.y, e_front.z, 0.f);
-                    Step st;
-                    path_step<GENERIC>(sc, tb, v, mp, seed, s, base2d + 3u + (n - 1u), n, pp.depth, pp.russian, cum, c1, st);
-                    if (st.go) {
-                        cont = true;
-                        nA = make_float4(st.no.x, st.no.y, st.no.z, st.nd.x);
-                        nB = make_float4(st.nd.y, st.nd.z, h.w, __uint_as_float(slot));
-                        thr[slot] = make_float4(st.cum.x, st.cum.y, st.cum.z, __uint_as_float((n & 0xffffu) | (c1 << 16)));
-                    }
-                }
+                f_light = bxdf_value_slow(sc, (int)__float_as_uint(l0.w), qrot(lg2l, light_to_p), qrot(lg2l, lVr), luv);
+                f_point = bxdf_value_slow(sc, (int)mat_id, VrL, qrot(g2l, p_to_light), uv);
+            }
+            const f3 dd = pos - lpos;
+            const float G = fabsf(dot3(lightN, p_to_light)) / dot3(dd, dd);
+            const f3 rad = mk3(l3.x, l3.y, l3.z) * (f_light * f_point * G);
+            if (rad.x != 0.f || rad.y != 0.f || rad.z != 0.f) {
+                mask |= 1u << q;
+                rads[(size_t)q * bs + t] = make_float4(rad.x, rad.y, rad.z, 0.f);
             }
         }
-        const uint32_t pn = block_append(cont, &counters[RGK_CNT_QUEUE + bounce + 1], s_cnt, &s_base);
-        if (cont) { nextA[pn] = nA; nextB[pn] = nB; }
-        if (!GENERIC) {
-            const uint32_t pd = block_append(defer, &counters[RGK_CNT_GENERIC + bounce], s_cnt, &s_base);
-            if (defer) pp.generic[pd] = i;
+        if (__float_as_uint(c5.w) & 1u) { // front-facing and emitting
+            mask |= 0x100u;
+            jobs[2 * bs + t] = make_float4(mat.emission[0], mat.emission[1], mat.emission[2], 0.f);
         }
-        // ---- q = 0: NEE to the path's light (:427-460); q = 1..reverse: light vertex q-1 (:463-480)
-        for (uint32_t q = 0; q <= pp.reverse; q++) {
-            bool shadow = false;
-            float4 sA = make_float4(0, 0, 0, 0), sB = sA, sC = sA;
-            if (have) {
-                f3 from = mk3(0.f, 0.f, 0.f), rad = from;
-                bool candidate = false;
-                if (q == 0) {
-                    const float4 li = pp.light[slot];
-                    const DLight L = light_from_code(sc, mk3(li.x, li.y, li.z), __float_as_uint(li.w));
-                    if (L.type >= 0) {
-                        candidate = true;
-                        from = L.pos;
-                        const f3 dd = v.pos - L.pos;
-                        const f3 Vi = norm3(L.pos - v.pos);
-                        const f3 f = mat_value<GENERIC>(sc, (int)v.mat_id, v.mat, mp, qrot(v.g2l, Vi), v.VrL, v.uv);
-                        const float G = fabsf(dot3(v.lightN, Vi)) / dot3(dd, dd);
-                        const float kk = L.intensity * light_dir_factor(L, -Vi);
-                        rad = (L.color * mk3(kk, kk, kk)) * (f * G);
-                    }
-                } else {
-                    const float4 l3 = *lv_ptr(pp, q - 1, 3, slot);
-                    if (l3.w != 0.0f) {
-                        candidate = true;
-                        const float4 l0 = *lv_ptr(pp, q - 1, 0, slot), l1 = *lv_ptr(pp, q - 1, 1, slot), l2 = *lv_ptr(pp, q - 1, 2, slot);
-                        const f3 lpos = mk3(l0.x, l0.y, l0.z), lN = mk3(l1.x, l1.y, l1.z), lVr = mk3(l2.x, l2.y, l2.z);
-                        const float2 luv = make_float2(l1.w, l2.w);
-                        from = lpos;
-                        const f3 light_to_p = norm3(v.pos - lpos);
-                        const f3 p_to_light = -light_to_p;
-                        const quatf lg2l = rotation_between(lN, mk3(0.f, 0.f, 1.f));
-                        const f3 f_light = GENERIC ? bxdf_value_slow(sc, (int)__float_as_uint(l0.w), qrot(lg2l, light_to_p), qrot(lg2l, lVr), luv)
-                                                   : bxdf_value_fastkind(sc, mat_load(sc, __float_as_uint(l0.w)), *lv_ptr(pp, q - 1, 4, slot), *lv_ptr(pp, q - 1, 5, slot),
-                                                                         qrot(lg2l, light_to_p), qrot(lg2l, lVr));
-                        const f3 f_point = mat_value_at<GENERIC>(sc, (int)v.mat_id, v.mat, mp, v.VrL, qrot(v.g2l, p_to_light), v.uv);
-                        const f3 dd = v.pos - lpos;
-                        const float G = fabsf(dot3(v.lightN, p_to_light)) / dot3(dd, dd);
-                        rad = mk3(l3.x, l3.y, l3.z) * (f_light * f_point * G);
-                    }
-                }
-                pp.term[(size_t)q * pp.batch + slot] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (candidate && (rad.x != 0.f || rad.y != 0.f || rad.z != 0.f)) {
-                    const f3 diff = v.pos - from; // Ray(from, p.pos, 20 eps)
-                    const f3 sd = norm3(diff);
-                    shadow = true;
-                    sA = make_float4(from.x, from.y, from.z, sd.x);
-                    sB = make_float4(sd.y, sd.z, len3(diff) - eps * 20.0f, __uint_as_float(q * pp.batch + slot));
-                    sC = make_float4(rad.x, rad.y, rad.z, 0.0f + eps * 20.0f);
-                }
-            }
-            const uint32_t ps = block_append(shadow, &counters[RGK_CNT_SHADOW + bounce], s_cnt, &s_base);
-            if (shadow) { shA[ps] = sA; shB[ps] = sB; shC[ps] = sC; }
-        }
-    }
-}
-
-// ---- total_here = NEE + connections (+ emission), clamp, path_total += total_here * contribution (:422-496)
-__global__ __launch_bounds__(256) void k_finish_vertex(const PassParams pp, const uint32_t bounce, const float4* __restrict__ rayB,
-                                                        float4* __restrict__ tot, const uint32_t* __restrict__ counters) {
-    const uint32_t count = counters[RGK_CNT_QUEUE + bounce];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
-        const uint32_t slot = __float_as_uint(rayB[i].w);
-        const float4 fin = pp.vfin[slot];
-        if (fin.w == 0.0f) continue;
-        f3 total = mk3(0.f, 0.f, 0.f);
-        for (uint32_t q = 0; q <= pp.reverse; q++) {
-            const float4 t = pp.term[(size_t)q * pp.batch + slot];
-            total = total + mk3(t.x, t.y, t.z);
-        }
-        const float4 e = pp.vemit[slot];
-        if (e.x != 0.f || e.y != 0.f || e.z != 0.f) total = total + mk3(e.x, e.y, e.z);
-        total = clamp3(total, pp.clamp);
-        const f3 add = total * mk3(fin.x, fin.y, fin.z);
-        float4 t = tot[slot];
-        t.x = t.x + add.x; t.y = t.y + add.y; t.z = t.z + add.z;
-        tot[slot] = t;
-        pp.vfin[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+        jobs[t] = c0;
+        jobs[bs + t] = make_float4(c4.x, c4.y, c4.z, __uint_as_float(mask));
     }
 }

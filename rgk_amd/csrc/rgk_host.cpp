@@ -485,7 +485,10 @@ struct rgk_scene {
     // workspace
     size_t batch = 0;
     DevBuf<float4> rayA[2], rayB[2], hit, thr, tot, shA, shB, shC, pixsum, light;
-    DevBuf<float4> lstart, lv, term, vfin, vemit; // bidirectional state (reverse > 0)
+    DevBuf<float4> lstart, lv; // bidirectional state (reverse > 0)
+    DevBuf<uint32_t> hitlist;  // ... light sub-path: queue indices of the rays that hit (k_list_hits)
+    DevBuf<uint32_t> lvmask, connlist; // ... which light vertices a slot has; queue indices of the camera vertices with connections
+    DevBuf<float4> conn, jobs, rads;   // ... their records (k_shade<BDPT> -> k_connect) and the vertex queue of k_trace_shadow_jobs
     uint32_t batch_reverse = 0;
     DevBuf<float> htab;
     DevBuf<float2> nearfar;
@@ -518,7 +521,7 @@ struct rgk_scene {
         hdims.release(); hperm.release(); texrefs.release();
         for (int i = 0; i < 2; i++) { rayA[i].release(); rayB[i].release(); }
         hit.release(); thr.release(); tot.release(); shA.release(); shB.release(); shC.release(); pixsum.release();
-        light.release(); generic.release(); htab.release(); lstart.release(); lv.release(); term.release(); vfin.release(); vemit.release();
+        light.release(); generic.release(); htab.release(); lstart.release(); lv.release(); hitlist.release(); lvmask.release(); connlist.release(); conn.release(); jobs.release(); rads.release();
         nearfar.release(); counters.release(); pix_xy.release(); pix_seed.release(); tile_buf.release(); stats.release(); entry.release(); entry_cap.release(); lentry.release(); trange.release(); lbox.release();
         scratch_f.release(); scratch_u.release();
         if (stream) (void)hipStreamDestroy(stream);
@@ -535,15 +538,19 @@ int ensure_workspace(rgk_scene* s, size_t paths, uint32_t reverse = 0) {
     if (!rc) rc = s->hit.alloc(paths);
     if (!rc) rc = s->thr.alloc(paths);
     if (!rc) rc = s->tot.alloc(paths);
-    if (!rc) rc = s->shA.alloc(paths * (reverse + 1)); // BDPT: 1 + reverse shadow rays per camera vertex
-    if (!rc) rc = s->shB.alloc(paths * (reverse + 1));
-    if (!rc) rc = s->shC.alloc(paths * (reverse + 1));
+    // plain shadow queue: one ray {shA, shB, shC} per path and bounce
+    if (!rc) rc = s->shA.alloc(paths);
+    if (!rc) rc = s->shB.alloc(paths);
+    if (!rc) rc = s->shC.alloc(paths);
     if (reverse) {
         if (!rc) rc = s->lstart.alloc(paths);
         if (!rc) rc = s->lv.alloc(paths * RGK_LV_FLOAT4 * reverse);
-        if (!rc) rc = s->term.alloc(paths * (reverse + 1));
-        if (!rc) rc = s->vfin.alloc(paths);
-        if (!rc) rc = s->vemit.alloc(paths);
+        if (!rc) rc = s->hitlist.alloc(paths);
+        if (!rc) rc = s->lvmask.alloc(paths);
+        if (!rc) rc = s->connlist.alloc(paths);
+        if (!rc) rc = s->conn.alloc(paths * 6);                  // the record a camera vertex with connections leaves
+        if (!rc) rc = s->jobs.alloc(paths * 4);                  // vertex queue: {vertex}{contribution, mask}{emission}{NEE ray start}
+        if (!rc) rc = s->rads.alloc(paths * ((size_t)reverse + 1)); // ... and one radiance per ray
     }
     if (!rc) rc = s->light.alloc(paths);
     if (!rc) rc = s->generic.alloc(paths);
@@ -1102,7 +1109,9 @@ static void make_camera(const rgk_camera* c, DevCamera& o) { // the members Rend
 // configuration whose paths carry 3.5x the state).  RGK_WORKSPACE_GB / RGK_BATCH_PATHS override.
 static size_t batch_paths(uint32_t reverse) {
     if (const char* e = getenv("RGK_BATCH_PATHS")) return std::max<size_t>(1024, strtoull(e, nullptr, 10));
-    const size_t per_path = 180 + (reverse ? 48 + 16 * RGK_LV_FLOAT4 * (size_t)reverse + 16 * ((size_t)reverse + 1) + 48 * (size_t)reverse : 0);
+    // rays 2 x 32, hit 16, state 16, sum 16, light 16, shadow queue 48, generic list 4; bidirectional: + light start 16, light
+    // vertices, hit list 4, and the vertex queue's 2 + (1 + reverse) more float4 than a ray's 3
+    const size_t per_path = 180 + (reverse ? 16 + 16 * RGK_LV_FLOAT4 * (size_t)reverse + 12 + 16 * (6 + 4 + (size_t)reverse + 1) : 0);
     const char* g = getenv("RGK_WORKSPACE_GB");
     double gb = g ? atof(g) : (reverse ? 160.0 : 96.0); // bidirectional paths carry 3.5x the state: 765 -> 781 Mpaths/s
     if (!g) { // a shared or smaller card: never plan for more than 60 % of what is free right now
@@ -1226,16 +1235,16 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
     PassParams pp{};
     pp.multisample = prm->multisample; pp.depth = prm->depth; pp.xres = prm->xres; pp.yres = prm->yres;
     pp.clamp = prm->clamp; pp.russian = prm->russian; pp.bumpmap_scale = prm->bumpmap_scale; pp.reverse = R;
-    pp.lstart = s->lstart.p; pp.lv = s->lv.p; pp.term = s->term.p; pp.vfin = s->vfin.p; pp.vemit = s->vemit.p;
+    pp.lstart = s->lstart.p; pp.lv = s->lv.p; pp.hitlist = s->hitlist.p; pp.lvmask = s->lvmask.p; pp.conn = s->conn.p; pp.connlist = s->connlist.p;
     pp.batch = (uint32_t)s->batch;
     pp.pix_xy = s->pix_xy.p; pp.pix_seed = s->pix_seed.p;
     pp.entry = s->entry.p; // (null when switched off; only the unidirectional bounce-0 launch reads it)
     pp.entry_cap = s->entry_cap.p;
-    bool cap_entries = s->entry.p != nullptr && R == 0;
+    bool cap_entries = s->entry.p != nullptr;
     { const char* ce = std::getenv("RGK_ENTRY_CAP"); if (ce && ce[0] == '0') cap_entries = false; }
     pp.lentry = nullptr;
     // one point / sphere light and nothing else that emits: every first-vertex shadow ray starts there (k_entry_points_light)
-    bool light_entry = s->entry.p && R == 0 && s->dev.n_pointlights == 1 && s->dev.n_areal == 0;
+    bool light_entry = s->entry.p && s->dev.n_pointlights == 1 && s->dev.n_areal == 0;
     { const char* le = std::getenv("RGK_LIGHT_ENTRY"); if (le && le[0] == '0') light_entry = false; }
     if (light_entry) {
         const size_t groups = ((size_t)P + RGK_ENTRY_PIX - 1) / RGK_ENTRY_PIX + 1;
@@ -1282,7 +1291,24 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
             const uint32_t n0 = pp.npix * pp.ns;
             uint32_t* cn = s->counters.p;                   // camera-phase counters
             uint32_t* cl = s->counters.p + RGK_CNT_TOTAL;   // light-phase counters
-            if (R == 0) {
+            if (R > 0) {
+                // light sub-path first (its sampler dimensions are fixed, DESIGN.md 3), splats straight into the accumulator
+                rgk_launch_set_bound(n0, n0);
+                TIMED(3, rgk_launch_init_counters(st, cl, n0));
+                TIMED(3, rgk_launch_raygen_light(st, s->dev, cam, pp, s->rayA[0].p, s->rayB[0].p, s->thr.p));
+                for (uint32_t k = 0; k < R; k++) {
+                    int q = k & 1;
+                    TIMED(0, rgk_launch_trace_closest(st, s->dev, s->tcfg, count_stats, s->rayA[q].p, s->rayB[q].p, nullptr, s->hit.p,
+                                                      cl + RGK_CNT_QUEUE + k, cl + RGK_CNT_FETCH_T + k, s->stats.p));
+                    TIMED(3, rgk_launch_list_hits(st, s->hit.p, cl + RGK_CNT_QUEUE + k, s->hitlist.p, cl + RGK_CNT_HITS + k));
+                    TIMED(2, rgk_launch_shade_light(st, s->dev, cam, pp, k, s->rayA[q].p, s->rayB[q].p, s->hit.p, s->thr.p,
+                                                    s->rayA[q ^ 1].p, s->rayB[q ^ 1].p, s->shA.p, s->shB.p, s->shC.p, cl));
+                    TIMED(1, rgk_launch_trace_shadow(st, s->dev, s->tcfg, count_stats, s->shA.p, s->shB.p, s->shC.p, nullptr, nullptr,
+                                                     RGK_SHADOW_SPLAT, d_accum_rgb, cl + RGK_CNT_SHADOW + k, cl + RGK_CNT_FETCH_S + k, s->stats.p));
+                }
+            }
+            {   // the camera path: the same pipeline for uni- and bidirectional rounds (R > 0: vertices with connections take
+                // the record route -- k_shade<BDPT> -> k_connect -> k_trace_shadow_jobs -- beside the plain NEE rays)
                 TIMED(3, rgk_launch_init_counters(st, cn, n0));
                 uint32_t ub = n0; // upper bound on bounce b's queue
                 for (uint32_t b = 0; b < prm->depth && ub > 0; b++) {
@@ -1322,46 +1348,17 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
                         }
                     }
                     TIMED(2, rgk_launch_shade(st, s->dev, cam, pp, b, s->rayA[q].p, s->rayB[q].p, s->hit.p, s->thr.p, s->tot.p,
-                                              s->rayA[q ^ 1].p, s->rayB[q ^ 1].p, s->shA.p, s->shB.p, s->shC.p, cn));
+                                              s->rayA[q ^ 1].p, s->rayB[q ^ 1].p, s->shA.p, s->shB.p, s->shC.p, cn, R > 0));
+                    if (R > 0) TIMED(2, rgk_launch_connect(st, s->dev, pp, b, s->jobs.p, s->rads.p, cn));
                     if (b == 0 && light_entry)
                         TIMED(1, rgk_launch_trace_shadow_first(st, s->dev, pp, s->tcfg, count_stats, s->shA.p, s->shB.p, s->shC.p, s->tot.p,
                                                                cn + RGK_CNT_SHADOW + b, cn + RGK_CNT_FETCH_S + b, s->stats.p));
                     else
                         TIMED(1, rgk_launch_trace_shadow(st, s->dev, s->tcfg, count_stats, s->shA.p, s->shB.p, s->shC.p, s->tot.p, nullptr,
                                                          RGK_SHADOW_ADD, nullptr, cn + RGK_CNT_SHADOW + b, cn + RGK_CNT_FETCH_S + b, s->stats.p));
-                    if ((rc = stage_mark(stage_target + b + 1))) return rc;
-                    if (track && b >= 3 && (b & 1) && b + 1 < prm->depth && (rc = queue_len(cn + RGK_CNT_QUEUE + b + 1, ub))) return rc;
-                }
-            } else {
-                // light sub-path first (its sampler dimensions are fixed, DESIGN.md 3), splats straight into the accumulator
-                rgk_launch_set_bound(n0, n0);
-                TIMED(3, rgk_launch_init_counters(st, cl, n0));
-                TIMED(3, rgk_launch_raygen_light(st, s->dev, cam, pp, s->rayA[0].p, s->rayB[0].p, s->thr.p));
-                for (uint32_t k = 0; k < R; k++) {
-                    int q = k & 1;
-                    TIMED(0, rgk_launch_trace_closest(st, s->dev, s->tcfg, count_stats, s->rayA[q].p, s->rayB[q].p, nullptr, s->hit.p,
-                                                      cl + RGK_CNT_QUEUE + k, cl + RGK_CNT_FETCH_T + k, s->stats.p));
-                    TIMED(2, rgk_launch_shade_light(st, s->dev, cam, pp, k, s->rayA[q].p, s->rayB[q].p, s->hit.p, s->thr.p,
-                                                    s->rayA[q ^ 1].p, s->rayB[q ^ 1].p, s->shA.p, s->shB.p, s->shC.p, cl));
-                    TIMED(1, rgk_launch_trace_shadow(st, s->dev, s->tcfg, count_stats, s->shA.p, s->shB.p, s->shC.p, nullptr, nullptr,
-                                                     RGK_SHADOW_SPLAT, d_accum_rgb, cl + RGK_CNT_SHADOW + k, cl + RGK_CNT_FETCH_S + k, s->stats.p));
-                }
-                TIMED(3, rgk_launch_init_counters(st, cn, n0));
-                TIMED(3, rgk_launch_raygen_camera(st, s->dev, cam, pp, s->rayA[0].p, s->rayB[0].p, s->thr.p, s->tot.p));
-                uint32_t ub = n0;
-                for (uint32_t b = 0; b < prm->depth && ub > 0; b++) {
-                    int q = b & 1;
-                    rgk_launch_set_bound(ub, (uint32_t)std::min<uint64_t>((uint64_t)ub * (R + 1), 0xffffffffull));
-                    if (b == 0 && pp.entry) // the camera rays are in the queue (k_shade_bdpt reads them there), but the walk remakes ray i from slot i and starts at the group's entry nodes
-                        TIMED(0, rgk_launch_trace_camera(st, s->dev, cam, pp, s->tcfg, count_stats, s->hit.p, cn + RGK_CNT_QUEUE, cn + RGK_CNT_FETCH_T, s->stats.p));
-                    else
-                        TIMED(0, rgk_launch_trace_closest(st, s->dev, s->tcfg, count_stats, s->rayA[q].p, s->rayB[q].p, nullptr, s->hit.p,
-                                                          cn + RGK_CNT_QUEUE + b, cn + RGK_CNT_FETCH_T + b, s->stats.p));
-                    TIMED(2, rgk_launch_shade_bdpt(st, s->dev, cam, pp, b, s->rayA[q].p, s->rayB[q].p, s->hit.p, s->thr.p, s->tot.p,
-                                                   s->rayA[q ^ 1].p, s->rayB[q ^ 1].p, s->shA.p, s->shB.p, s->shC.p, cn));
-                    TIMED(1, rgk_launch_trace_shadow(st, s->dev, s->tcfg, count_stats, s->shA.p, s->shB.p, s->shC.p, s->term.p, nullptr,
-                                                     RGK_SHADOW_CELL, nullptr, cn + RGK_CNT_SHADOW + b, cn + RGK_CNT_FETCH_S + b, s->stats.p));
-                    TIMED(3, rgk_launch_finish_vertex(st, pp, b, s->rayB[q].p, s->tot.p, cn));
+                    if (R > 0) // (after the plain rays: both add into the slot sums, a slot has a vertex in ONE of the two queues)
+                        TIMED(1, rgk_launch_trace_shadow_jobs(st, s->dev, pp, s->tcfg, count_stats, s->jobs.p, s->rads.p, s->tot.p,
+                                                              cn + RGK_CNT_CONN + b, cn + RGK_CNT_FETCH_J + b, cn + RGK_CNT_SRAYS + b, s->stats.p));
                     if ((rc = stage_mark(stage_target + b + 1))) return rc;
                     if (track && b >= 3 && (b & 1) && b + 1 < prm->depth && (rc = queue_len(cn + RGK_CNT_QUEUE + b + 1, ub))) return rc;
                 }
@@ -1371,7 +1368,7 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
             if ((rc = stage_mark(stage_target))) return rc;
             HIPCHK(hipMemcpyAsync(s->h_counters, s->counters.p, 2 * RGK_CNT_TOTAL * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
-            for (uint32_t b = 0; b < prm->depth; b++) { path_rays += s->h_counters[RGK_CNT_QUEUE + b]; shadow_rays += s->h_counters[RGK_CNT_SHADOW + b]; }
+            for (uint32_t b = 0; b < prm->depth; b++) { path_rays += s->h_counters[RGK_CNT_QUEUE + b]; shadow_rays += s->h_counters[RGK_CNT_SHADOW + b] + s->h_counters[RGK_CNT_SRAYS + b]; }
             for (uint32_t k = 0; k < R; k++) { path_rays += s->h_counters[RGK_CNT_TOTAL + RGK_CNT_QUEUE + k]; shadow_rays += s->h_counters[RGK_CNT_TOTAL + RGK_CNT_SHADOW + k]; }
         }
     }

@@ -21,11 +21,14 @@
 #define RGK_CNT_FETCH_T 128 // [b]  work-fetch cursor of k_trace_closest at bounce b
 #define RGK_CNT_FETCH_S 192 // [b]  work-fetch cursor of k_trace_shadow at bounce b
 #define RGK_CNT_GENERIC 256 // [b]  vertices of bounce b left to the generic-BxDF shade launch
-#define RGK_CNT_TOTAL 320
+#define RGK_CNT_HITS 320    // [k]  light sub-path: rays of bounce k that hit something (k_list_hits)
+#define RGK_CNT_SRAYS 384   // [b]  bidirectional rounds: shadow rays traced at bounce b (RGK_CNT_SHADOW counts the vertices queued)
+#define RGK_CNT_CONN 448    // [b]  bidirectional rounds: camera vertices of bounce b with connections (k_connect; = entries of the vertex queue)
+#define RGK_CNT_FETCH_J 512 // [b]  work-fetch cursor of k_trace_shadow_jobs at bounce b
+#define RGK_CNT_TOTAL 576
 
 // what k_trace_shadow does with a visible ray's payload
 #define RGK_SHADOW_ADD 0   // tot[slot] += radiance                     (uni-directional path)
-#define RGK_SHADOW_CELL 1  // cells[target] = radiance                  (BDPT: term[q][slot])
 #define RGK_SHADOW_SPLAT 2 // atomicAdd(accum_rgb[pixel], radiance)     (BDPT: light-tracing side effect)
 
 #ifndef RGK_ENTRY_K
@@ -58,9 +61,10 @@ struct PassParams {
     // bidirectional state (reverse > 0), null otherwise; per slot with stride `batch`
     float4* lstart;           // light_at_path_start.rgb
     float4* lv;               // light vertices: lv[(k*RGK_LV_FLOAT4 + c) * batch + slot], c: see RGK_LV_FLOAT4
-    float4* term;             // term[q * batch + slot]: q = 0 NEE, q = 1..reverse connections
-    float4* vfin;             // {contribution.rgb, 1 if the slot has a vertex awaiting k_finish_vertex}
-    float4* vemit;            // emission of that vertex if front-facing
+    uint32_t* hitlist;        // light sub-path: queue indices of the rays that hit something (k_list_hits)
+    uint32_t* lvmask;         // per slot: bit k = light vertex k exists, bit 7 = one of them has a generic-route material
+    float4* conn;             // camera vertices with connections: conn[c * batch + i] for queue index i, c < 6 (k_shade<BDPT> -> k_connect)
+    uint32_t* connlist;       // ... and the queue indices that have one
     uint32_t batch;
     uint32_t* generic;        // queue indices of the vertices whose material takes the generic BxDF route (k_shade)
 };
@@ -102,18 +106,16 @@ void rgk_launch_trace_shadow_first(hipStream_t st, const DevScene& sc, const Pas
                                    const float4* shC, float4* tot, const uint32_t* count_ptr, uint32_t* fetch, unsigned long long* stats);
 void rgk_launch_raygen_light(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, float4* rayA, float4* rayB,
                              float4* thr);
-void rgk_launch_raygen_camera(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, float4* rayA, float4* rayB,
-                              float4* thr, float4* tot);
 void rgk_launch_shade_light(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t k, const float4* rayA,
                             const float4* rayB, const float4* hit, float4* thr, float4* nextA, float4* nextB, float4* shA, float4* shB,
                             float4* shC, uint32_t* counters);
-void rgk_launch_shade_bdpt(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t bounce,
-                           const float4* rayA, const float4* rayB, const float4* hit, float4* thr, float4* tot, float4* nextA, float4* nextB,
-                           float4* shA, float4* shB, float4* shC, uint32_t* counters);
-void rgk_launch_finish_vertex(hipStream_t st, const PassParams& pp, uint32_t bounce, const float4* rayB, float4* tot, const uint32_t* counters);
+void rgk_launch_list_hits(hipStream_t st, const float4* hit, const uint32_t* count_ptr, uint32_t* list, uint32_t* list_count);
+void rgk_launch_connect(hipStream_t st, const DevScene& sc, const PassParams& pp, uint32_t bounce, float4* jobs, float4* rads, const uint32_t* counters);
+void rgk_launch_trace_shadow_jobs(hipStream_t st, const DevScene& sc, const PassParams& pp, const RgkTraceCfg& tc, bool count_stats, const float4* jobs, const float4* rads,
+                                  float4* tot, const uint32_t* count_ptr, uint32_t* fetch, uint32_t* rays_out, unsigned long long* stats);
 void rgk_launch_shade(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t bounce, const float4* rayA,
                       const float4* rayB, const float4* hit, float4* thr, float4* tot, float4* nextA, float4* nextB, float4* shA,
-                      float4* shB, float4* shC, uint32_t* counters);
+                      float4* shB, float4* shC, uint32_t* counters, bool bdpt = false);
 void rgk_launch_resolve(hipStream_t st, const PassParams& pp, const float4* tot, float4* pixsum, float* accum_rgb, uint32_t* accum_count);
 void rgk_launch_pack_rays(hipStream_t st, uint32_t n, const float* rays, const int32_t* ignore, float4* rayA, float4* rayB, float2* nearfar);
 void rgk_launch_pack_visibility(hipStream_t st, const DevScene& sc, uint32_t n, const float* a, const float* b, float4* shA, float4* shB,

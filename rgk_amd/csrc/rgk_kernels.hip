@@ -37,7 +37,13 @@
 // implicit {1, 1, 1 | n = 0, 1-D counter = 1}, the path's ONE light is sampled here (TracePath: areal_sample, (lightdir_sample),
 // GetRandomLight(Get2D, Get1D, areal_sample) -- path_tracer.cpp:315-322) and kept per slot for the later bounces of paths that
 // go on, and the slot's radiance sum STARTS here (written, not read-modified: nothing zeroes it beforehand).
-template <bool GENERIC, bool FIRST>
+// BDPT = true: a camera-path vertex of a bidirectional round (reverse > 0).  The same vertex code; but where the slot's light
+// sub-path has vertices to connect to (pp.lvmask) or the vertex emits, its total is clamp(NEE + connections + emission) -- the
+// clamp spans all of them (path_tracer.cpp:422-496) -- so instead of its own shadow ray the vertex leaves a RECORD
+// (pp.conn[c * batch + i], i = its queue index, listed in pp.connlist) for k_connect (rgk_bdpt.h), which evaluates the
+// connections and queues the vertex for k_trace_shadow_jobs.  Most slots have no light vertex (a light far outside the
+// geometry: its first ray must hit the scene at all), and those vertices are shaded exactly like a unidirectional one.
+template <bool GENERIC, bool FIRST, bool BDPT = false>
 __global__ __launch_bounds__(RGK_SHADE_BLOCK, RGK_SHADE_WAVES) void k_shade(const DevScene sc, const DevCamera cam, const PassParams pp, const uint32_t bounce,
                                                             const float4* __restrict__ rayA, const float4* __restrict__ rayB,
                                                             const float4* __restrict__ hit, float4* __restrict__ thr, float4* __restrict__ tot,
@@ -51,14 +57,14 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, RGK_SHADE_WAVES) void k_shade(cons
     const int lane = threadIdx.x & 63;
     const float eps = sc.epsilon;
     const SamplerTab tb = {pp.htab, pp.multisample};
-    __shared__ uint32_t s_cnt[3][RGK_SHADE_BLOCK / 64];
-    __shared__ uint32_t s_base[3];
+    __shared__ uint32_t s_cnt[4][RGK_SHADE_BLOCK / 64];
+    __shared__ uint32_t s_base[4];
     lut_lds_fill(sc);
     // workgroup-uniform trip count (the compaction below synchronises the workgroup)
     for (uint32_t base = blockIdx.x * RGK_SHADE_BLOCK; base < count; base += gridDim.x * RGK_SHADE_BLOCK) {
         const bool valid = base + threadIdx.x < count;
         const uint32_t i = !valid ? 0u : (GENERIC ? pp.generic[base + threadIdx.x] : base + threadIdx.x);
-        bool cont = false, shadow = false, defer = false;
+        bool cont = false, shadow = false, defer = false, conn = false;
         float4 nA = make_float4(0, 0, 0, 0), nB = nA, sA = nA, sB = nA, sC = nA;
         if (valid) {
             const float4 h = hit[i];
@@ -193,8 +199,10 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, RGK_SHADE_WAVES) void k_shade(cons
                         f3 e_front = mk3(0.f, 0.f, 0.f);
                         if (dot3(faceN, Vr) > 0) e_front = mk3(mat.emission[0], mat.emission[1], mat.emission[2]);
                         const bool has_e = (e_front.x != 0.f) || (e_front.y != 0.f) || (e_front.z != 0.f);
+                        // bidirectional: light vertices to connect to (bits 0..6), or an emitting vertex -> the record route
+                        if (BDPT) conn = ((pp.lvmask[slot] & 0x7fu) != 0u) || has_e;
                         f3 B = mk3(0.f, 0.f, 0.f);
-                        if (has_e) {
+                        if (has_e && !conn) {
                             B = clamp3(mk3(0.f, 0.f, 0.f) + e_front, pp.clamp) * contribution;
                             if (FIRST && !GENERIC) tot0 = mk3(0.f + B.x, 0.f + B.y, 0.f + B.z);
                             else {
@@ -203,6 +211,7 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, RGK_SHADE_WAVES) void k_shade(cons
                                 tot[slot] = t;
                             }
                         }
+                        f3 out = mk3(0.f, 0.f, 0.f); // NEE radiance before visibility, clamp and contribution
                         if (L.type >= 0 && !nee_dead) {
                             const f3 diff = pos - L.pos; // Ray(light.pos, p.pos, 20 eps), src/ray.hpp:15-22
                             const f3 sd = norm3(diff);
@@ -212,15 +221,26 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, RGK_SHADE_WAVES) void k_shade(cons
                             const float G = fabsf(dot3(lightN, Vi)) / dot3(diff, diff);
                             const float k = L.intensity * light_dir_factor(L, -Vi);
                             const f3 inc = L.color * mk3(k, k, k);
-                            const f3 out = inc * (f * G);
-                            f3 A = clamp3((mk3(0.f, 0.f, 0.f) + out) + e_front, pp.clamp) * contribution;
-                            f3 rad = has_e ? A - B : A;
-                            if (rad.x != 0.f || rad.y != 0.f || rad.z != 0.f) {
-                                shadow = true;
-                                sA = make_float4(L.pos.x, L.pos.y, L.pos.z, sd.x);
-                                sB = make_float4(sd.y, sd.z, slen - eps * 20.0f, __uint_as_float(slot));
-                                sC = make_float4(rad.x, rad.y, rad.z, 0.0f + eps * 20.0f);
+                            out = inc * (f * G);
+                            if (!conn) {
+                                f3 A = clamp3((mk3(0.f, 0.f, 0.f) + out) + e_front, pp.clamp) * contribution;
+                                f3 rad = has_e ? A - B : A;
+                                if (rad.x != 0.f || rad.y != 0.f || rad.z != 0.f) {
+                                    shadow = true;
+                                    sA = make_float4(L.pos.x, L.pos.y, L.pos.z, sd.x);
+                                    sB = make_float4(sd.y, sd.z, slen - eps * 20.0f, __uint_as_float(slot));
+                                    sC = make_float4(rad.x, rad.y, rad.z, 0.0f + eps * 20.0f);
+                                }
                             }
+                        }
+                        if (BDPT && conn) { // everything k_connect needs to evaluate this vertex's material towards a light vertex
+                            const size_t bs = pp.batch;
+                            pp.conn[i] = make_float4(pos.x, pos.y, pos.z, __uint_as_float(slot));
+                            pp.conn[bs + i] = make_float4(lightN.x, lightN.y, lightN.z, __uint_as_float(mat_id));
+                            pp.conn[2 * bs + i] = make_float4(g2l.x, g2l.y, g2l.z, g2l.w);
+                            pp.conn[3 * bs + i] = make_float4(VrL.x, VrL.y, VrL.z, uv.x);
+                            pp.conn[4 * bs + i] = make_float4(contribution.x, contribution.y, contribution.z, uv.y);
+                            pp.conn[5 * bs + i] = make_float4(out.x, out.y, out.z, __uint_as_float(has_e ? 1u : 0u));
                         }
                     }
                     // ---- continuation, path_tracer.cpp:275-300
@@ -251,23 +271,26 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, RGK_SHADE_WAVES) void k_shade(cons
         {
             // Wave ballot + prefix popcount inside the wave, the waves of the workgroup add up through LDS, and ONE
             // atomic per workgroup and queue reserves the range.
-            const unsigned long long m = __ballot(cont), ms = __ballot(shadow), md = __ballot(defer);
+            const unsigned long long m = __ballot(cont), ms = __ballot(shadow), md = __ballot(defer), mc = BDPT ? __ballot(conn) : 0ull;
             const int w = threadIdx.x >> 6;
-            if (lane == 0) { s_cnt[0][w] = __popcll(m); s_cnt[1][w] = __popcll(ms); s_cnt[2][w] = __popcll(md); }
+            if (lane == 0) { s_cnt[0][w] = __popcll(m); s_cnt[1][w] = __popcll(ms); s_cnt[2][w] = __popcll(md); if (BDPT) s_cnt[3][w] = __popcll(mc); }
             __syncthreads();
             if (threadIdx.x == 0) {
-                uint32_t t0 = 0, t1 = 0, t2 = 0;
+                uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
                 for (int k = 0; k < RGK_SHADE_BLOCK / 64; k++) {
                     uint32_t a = s_cnt[0][k], b = s_cnt[1][k], c = s_cnt[2][k];
                     s_cnt[0][k] = t0; s_cnt[1][k] = t1; s_cnt[2][k] = t2;
                     t0 += a; t1 += b; t2 += c;
+                    if (BDPT) { uint32_t e = s_cnt[3][k]; s_cnt[3][k] = t3; t3 += e; }
                 }
                 s_base[0] = t0 ? atomicAdd(&counters[RGK_CNT_QUEUE + bounce + 1], t0) : 0u;
                 s_base[1] = t1 ? atomicAdd(&counters[RGK_CNT_SHADOW + bounce], t1) : 0u;
                 s_base[2] = t2 ? atomicAdd(&counters[RGK_CNT_GENERIC + bounce], t2) : 0u;
+                if (BDPT) s_base[3] = t3 ? atomicAdd(&counters[RGK_CNT_CONN + bounce], t3) : 0u;
             }
             __syncthreads();
             if (!GENERIC && defer) pp.generic[s_base[2] + s_cnt[2][w] + __popcll(md & ((1ull << lane) - 1ull))] = i;
+            if (BDPT && conn) pp.connlist[s_base[3] + s_cnt[3][w] + __popcll(mc & ((1ull << lane) - 1ull))] = i;
             if (cont) {
                 uint32_t p = s_base[0] + s_cnt[0][w] + __popcll(m & ((1ull << lane) - 1ull));
                 nextA[p] = nA; nextB[p] = nB;
@@ -806,10 +829,16 @@ void rgk_launch_trace_shadow_first(hipStream_t st, const DevScene& sc, const Pas
 
 void rgk_launch_shade(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t bounce, const float4* rayA,
                       const float4* rayB, const float4* hit, float4* thr, float4* tot, float4* nextA, float4* nextB, float4* shA,
-                      float4* shB, float4* shC, uint32_t* counters) {
+                      float4* shB, float4* shC, uint32_t* counters, bool bdpt) {
     const int g1 = bounded_grid(256 * 4 * 512 / RGK_SHADE_BLOCK, g_bound, RGK_SHADE_BLOCK), g2 = bounded_grid(256 * 2 * 512 / RGK_SHADE_BLOCK, g_bound, RGK_SHADE_BLOCK);
     // the second launch shades the vertices the first one listed (materials on the generic BxDF route); it returns at once when there are none
-    if (bounce == 0) {
+    if (bdpt && bounce == 0) {
+        k_shade<false, true, true><<<g1, RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
+        k_shade<true, true, true><<<g2, RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
+    } else if (bdpt) {
+        k_shade<false, false, true><<<g1, RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
+        k_shade<true, false, true><<<g2, RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
+    } else if (bounce == 0) {
         k_shade<false, true><<<g1, RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
         k_shade<true, true><<<g2, RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
     } else {
@@ -849,22 +878,19 @@ void rgk_launch_raygen_light(hipStream_t st, const DevScene& sc, const DevCamera
                              float4* thr) {
     k_raygen_light<<<slot_grid(pp), 256, 0, st>>>(sc, cam, pp, rayA, rayB, thr);
 }
-void rgk_launch_raygen_camera(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, float4* rayA, float4* rayB,
-                              float4* thr, float4* tot) {
-    k_raygen_camera<<<slot_grid(pp), 256, 0, st>>>(sc, cam, pp, rayA, rayB, thr, tot);
-}
 void rgk_launch_shade_light(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t k, const float4* rayA,
                             const float4* rayB, const float4* hit, float4* thr, float4* nextA, float4* nextB, float4* shA, float4* shB,
                             float4* shC, uint32_t* counters) {
     k_shade_light<false><<<bounded_grid(256 * 4 * 512 / RGK_SHADE_BLOCK, g_bound, RGK_SHADE_BLOCK), RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, k, rayA, rayB, hit, thr, nextA, nextB, shA, shB, shC, counters);
     k_shade_light<true><<<bounded_grid(256 * 2 * 512 / RGK_SHADE_BLOCK, g_bound, RGK_SHADE_BLOCK), RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, k, rayA, rayB, hit, thr, nextA, nextB, shA, shB, shC, counters);
 }
-void rgk_launch_shade_bdpt(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t bounce,
-                           const float4* rayA, const float4* rayB, const float4* hit, float4* thr, float4* tot, float4* nextA, float4* nextB,
-                           float4* shA, float4* shB, float4* shC, uint32_t* counters) {
-    k_shade_bdpt<false><<<bounded_grid(256 * 4 * 512 / RGK_SHADE_BLOCK, g_bound, RGK_SHADE_BLOCK), RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
-    k_shade_bdpt<true><<<bounded_grid(256 * 2 * 512 / RGK_SHADE_BLOCK, g_bound, RGK_SHADE_BLOCK), RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, bounce, rayA, rayB, hit, thr, tot, nextA, nextB, shA, shB, shC, counters);
+void rgk_launch_connect(hipStream_t st, const DevScene& sc, const PassParams& pp, uint32_t bounce, float4* jobs, float4* rads, const uint32_t* counters) {
+    k_connect<<<bounded_grid(256 * 8, g_bound, 256), 256, RGK_LDS_SHADE_BYTES, st>>>(sc, pp, bounce, jobs, rads, counters);
 }
-void rgk_launch_finish_vertex(hipStream_t st, const PassParams& pp, uint32_t bounce, const float4* rayB, float4* tot, const uint32_t* counters) {
-    k_finish_vertex<<<bounded_grid(256 * 8, g_bound, 256), 256, 0, st>>>(pp, bounce, rayB, tot, counters);
+void rgk_launch_list_hits(hipStream_t st, const float4* hit, const uint32_t* count_ptr, uint32_t* list, uint32_t* list_count) {
+    k_list_hits<<<bounded_grid(256 * 4 * 512 / RGK_SHADE_BLOCK, g_bound, RGK_SHADE_BLOCK), RGK_SHADE_BLOCK, 0, st>>>(hit, count_ptr, list, list_count);
+}
+void rgk_launch_trace_shadow_jobs(hipStream_t st, const DevScene& sc, const PassParams& pp, const RgkTraceCfg& tc, bool count_stats, const float4* jobs, const float4* rads,
+                                  float4* tot, const uint32_t* count_ptr, uint32_t* fetch, uint32_t* rays_out, unsigned long long* stats) {
+    RGK_TRACE_DISPATCH(k_trace_shadow_jobs, g_bound_shadow, sc, pp, jobs, rads, tot, count_ptr, fetch, rays_out, stats, tc.ovf)
 }

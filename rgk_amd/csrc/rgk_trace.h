@@ -31,6 +31,9 @@
 #ifndef RGK_TRACE_WAVES
 #define RGK_TRACE_WAVES 8 // waves per SIMD the 16-LDS-entry traversal kernels are compiled for (64 VGPRs); the 32-entry ones are LDS-bound at 5
 #endif
+#ifndef RGK_JOB_FINISH_ATOMIC
+#define RGK_JOB_FINISH_ATOMIC 0 // the vertex total into the slot sum as three float atomics instead of a read-modify-write
+#endif
 #ifndef RGK_REFILL_BELOW
 #define RGK_REFILL_BELOW 24 // refill a wave when at most this many lanes still hold a ray (swept 8..60 with the majority walk: 24 best)
 #endif
@@ -131,14 +134,25 @@ __device__ __forceinline__ float cvt_ubyte(uint32_t w, int c) { return (float)((
 // STACK: entries the tree can need (host bound); LDSN <= STACK of them live in LDS, the rest -- reached only on the
 // deepest walks of a deep tree -- in a per-lane global overflow area, so that a deep tree does not halve the occupancy.
 // RAYGEN (closest hit, bounce 0): there is no ray queue -- ray i is the camera ray of path slot i, made here.
-template <bool ANY, bool COUNT, int STACK, int LDSN, bool RAYGEN = false>
+// JOB (any hit, bidirectional rounds): a queue entry is not a ray but a camera-path VERTEX with its 1 + reverse shadow rays --
+// NEE to the path's light and the connections to the path's light vertices (path_tracer.cpp:427-480).  They all END at the
+// vertex and START at points the slot already holds (pp.light, pp.lv), so the entry carries only the vertex, its contribution,
+// and one radiance per ray: q0[i] = {p.xyz, slot}, q0[batch + i] = {contribution.rgb, mask}, q0[2 batch + i] = {emission.rgb}
+// (read only when mask bit 8 says it is non-zero), q0[3 batch + i] = {where the NEE ray starts}, q1[q batch + i] = {radiance of
+// ray q} for the bits q set in mask.  The lane traces the flagged rays one after the other, adds the radiance of the visible
+// ones in the reference's order (NEE, light vertex 0, 1, ..., then the emission), clamps and adds total * contribution to the
+// slot's sum (:485-496) -- what took a term cell per ray and a pass of its own (k_finish_vertex, 12 % of a round) before.
+// Most vertices have the NEE ray only (a light sub-path needs its first ray to hit the scene), so everything that ray needs sits
+// behind the queue index alone: one round of loads per refill, as for a plain shadow ray.  Between rays a lane keeps the sum,
+// the mask and the queue index; the vertex itself is read again for the (rare) later rays and for the total.
+template <bool ANY, bool COUNT, int STACK, int LDSN, bool RAYGEN = false, bool JOB = false>
 __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float4* __restrict__ q0, const float4* __restrict__ q1,
                                                  const float4* __restrict__ q2, const float2* __restrict__ nearfar,
                                                  float4* __restrict__ hit, float4* __restrict__ tot, uint8_t* __restrict__ vis_out,
                                                  const int mode, float* __restrict__ splat_rgb,
                                                  const uint32_t count, uint32_t* __restrict__ fetch, int* __restrict__ stack, int* __restrict__ ovf, const uint32_t ostride,
                                                  uint32_t& n_nodes, uint32_t& n_tris, const DevCamera* cam = nullptr, const PassParams* pp = nullptr,
-                                                 unsigned long long* __restrict__ util = nullptr) {
+                                                 unsigned long long* __restrict__ util = nullptr, uint32_t* __restrict__ job_rays = nullptr) {
     const int lane = threadIdx.x & 63;
     uint32_t u_node_it = 0, u_leaf_it = 0, u_outer_it = 0, u_refill = 0; // COUNT: wave-level iteration counts (lane occupancy per phase)
     const int stride = RGK_TRACE_BLOCK;
@@ -155,15 +169,42 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
     f3 o = mk3(0.f, 0.f, 0.f), d = o, inv = o, rad = o;
     float tlo = 0.f, thi = 0.f, best_t = 0.f, best_a = 0.f, best_b = 0.f;
     int best_tri = -1, cur = STACK_SENTINEL, sp = 0;
+    // JOB: the sum over the vertex's visible rays so far, the rays still to trace (mask bits 0..7; bit 8: emissive)
+    f3 jsum = o;
+    uint32_t jmask = 0, n_job_rays = 0;
+    bool seg_pending = false;
 
 #define RGK_PUT(x) { if (LDSN >= STACK || sp < LDSN) stack[sp * stride] = (x); else ovf[(size_t)(sp - LDSN) * ostride] = (x); }
+// JOB: Ray(from, p, 20 eps) (src/ray.hpp:15-22) into the lane's traversal state; a ray that cannot touch the scene is visible at once
+#define RGK_JOB_RAY(from_, p_)                                                                                                         \
+    {                                                                                                                                  \
+        o = (from_);                                                                                                                   \
+        const f3 diff_ = (p_) - o;                                                                                                     \
+        d = norm3(diff_);                                                                                                              \
+        const float tf_ = len3(diff_) - eps * 20.0f, tn_ = 0.0f + eps * 20.0f;                                                         \
+        best_t = __builtin_inff(); best_tri = -1;                                                                                      \
+        sp = 0;                                                                                                                        \
+        float t0_, t1_;                                                                                                                \
+        const bool nan_ = (o.x != o.x) | (o.y != o.y) | (o.z != o.z) | (d.x != d.x) | (d.y != d.y) | (d.z != d.z);                     \
+        if (!nan_ && clip_to_scene(sc, o, d, tn_, tf_, t0_, t1_)) {                                                                    \
+            tlo = t0_ - eps; thi = t1_ + eps;                                                                                          \
+            inv = mk3(fminf(fmaxf(1.f / d.x, -1e30f), 1e30f), fminf(fmaxf(1.f / d.y, -1e30f), 1e30f), fminf(fmaxf(1.f / d.z, -1e30f), 1e30f)); \
+            cur = 0;                                                                                                                   \
+            seg_pending = false;                                                                                                       \
+        } else jsum = jsum + rad;                                                                                                      \
+    }
 #define RGK_POP() ((LDSN >= STACK || sp < LDSN) ? stack[sp * stride] : ovf[(size_t)(sp - LDSN) * ostride])
     for (;;) {
         // ------------------------------------------------ refill idle lanes
-        unsigned long long act = __ballot(active);
+        // (JOB: a lane whose ray is done but whose vertex has more waits like an idle lane -- `act` counts the lanes with a ray in
+        // flight -- and gets its next ray when the wave refills: setting a ray up means dependent loads, and doing that whenever
+        // any one lane finishes a ray stalls the other 63 each time)
+        const unsigned long long occ = __ballot(active);
+        unsigned long long act = JOB ? __ballot(active && !seg_pending) : occ;
         const int nact = __popcll(act);
         if (COUNT) u_outer_it++;
-        if (nact <= RGK_REFILL_BELOW && !(exhausted && w_next >= w_end)) {
+        const bool refill_now = nact <= RGK_REFILL_BELOW;
+        if (refill_now && !(exhausted && w_next >= w_end)) {
             if (COUNT) u_refill++;
             if (w_next >= w_end) {
                 uint32_t base = 0;
@@ -174,12 +215,26 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
             }
             const uint32_t avail = (w_end > w_next) ? (w_end - w_next) : 0u;
             if (avail) {
-                const unsigned long long idle = ~act;
+                const unsigned long long idle = ~occ;
                 const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
                 if (!active && rank < avail) {
                     idx = w_next + rank;
                     float tn = 0.0f, tf = 10000.0f; // Ray::near / Ray::far defaults, src/ray.hpp:25-26
                     uint32_t pixel_j = 0;
+                    if (JOB) { // a vertex: its NEE ray at once (everything it needs sits behind idx), later rays one by one below
+                        const float4 a = q0[idx], f0 = q0[3 * (size_t)pp->batch + idx], r0 = q1[idx];
+                        jmask = __float_as_uint(q0[(size_t)pp->batch + idx].w);
+                        jsum = mk3(0.f, 0.f, 0.f);
+                        ignore = 0xffffffffu;
+                        cur = STACK_SENTINEL; sp = 0;
+                        seg_pending = true; active = true;
+                        if (jmask & 1u) {
+                            jmask &= ~1u;
+                            n_job_rays += (uint32_t)__popcll(__ballot(true)); // wave-uniform: the lanes starting a ray here
+                            rad = mk3(r0.x, r0.y, r0.z);
+                            RGK_JOB_RAY(mk3(f0.x, f0.y, f0.z), mk3(a.x, a.y, a.z))
+                        }
+                    } else
                     if (RAYGEN) {
                         camera_ray_of_slot(*cam, *pp, idx, o, d, &pixel_j);
                         ignore = 0xffffffffu;
@@ -196,6 +251,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
                             if (nearfar) { float2 nf = nearfar[idx]; tn = nf.x; tf = nf.y; }
                         }
                     }
+                    if (!JOB) {
                     best_t = __builtin_inff(); best_tri = -1; best_a = 0.f; best_b = 0.f;
                     float t0, t1;
                     sp = 0;
@@ -242,9 +298,45 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
                         }
                     } else cur = STACK_SENTINEL; // misses the scene box: reported below as a miss
                     active = true;
+                    } // !JOB
                 }
-                const uint32_t taken = min(avail, (uint32_t)(64 - nact));
+                const uint32_t taken = min(avail, (uint32_t)(64 - __popcll(occ)));
                 w_next += taken;
+            }
+            act = __ballot(active);
+        }
+        if (JOB && refill_now) {
+            // lanes between two rays of their vertex: the next flagged ray, or -- none left -- the vertex's total into the slot sum
+            while (active && seg_pending) {
+                const float4 a = q0[idx]; // {p, slot}
+                const uint32_t jslot = __float_as_uint(a.w);
+                const uint32_t m = jmask & 0xffu;
+                if (m == 0u) {
+                    f3 total = jsum;
+                    if (jmask & 0x100u) { const float4 e = q0[2 * (size_t)pp->batch + idx]; total = total + mk3(e.x, e.y, e.z); }
+                    total = clamp3(total, pp->clamp);
+                    const float4 c = q0[(size_t)pp->batch + idx];
+                    const f3 add = total * mk3(c.x, c.y, c.z);
+#if RGK_JOB_FINISH_ATOMIC
+                    // (one vertex per slot and bounce, so each component sees ONE addition per launch -- the same bits as the
+                    // read-modify-write -- but nothing to wait for at a point where the whole wave waits)
+                    float* tp = reinterpret_cast<float*>(tot + jslot);
+                    unsafeAtomicAdd(tp, add.x); unsafeAtomicAdd(tp + 1, add.y); unsafeAtomicAdd(tp + 2, add.z);
+#else
+                    float4 t = tot[jslot]; // one vertex per slot and bounce: no race
+                    t.x = t.x + add.x; t.y = t.y + add.y; t.z = t.z + add.z;
+                    tot[jslot] = t;
+#endif
+                    active = false; seg_pending = false;
+                    break;
+                }
+                const uint32_t q = (uint32_t)__builtin_ctz(m);
+                jmask &= ~(1u << q);
+                n_job_rays += (uint32_t)__popcll(__ballot(true));
+                const float4 r = q1[(size_t)q * pp->batch + idx];
+                rad = mk3(r.x, r.y, r.z);
+                const float4 fr = (q == 0u) ? q0[3 * (size_t)pp->batch + idx] : pp->lv[(size_t)((q - 1u) * RGK_LV_FLOAT4) * pp->batch + jslot];
+                RGK_JOB_RAY(mk3(fr.x, fr.y, fr.z), mk3(a.x, a.y, a.z))
             }
             act = __ballot(active);
         }
@@ -378,6 +470,12 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
             ignore = 0xffffffffu;
             cur = 0; sp = 0;
         }
+        if (JOB) {
+            if (active && !seg_pending && cur == STACK_SENTINEL) { // this ray is done: the vertex's next one when the wave refills
+                if (best_tri < 0) jsum = jsum + rad;
+                seg_pending = true;
+            }
+        } else
         if (active && cur == STACK_SENTINEL) {
             if (!ANY) hit[idx] = make_float4(best_t, best_a, best_b, __int_as_float(best_tri));
             else if (vis_out) vis_out[idx] = best_tri < 0;
@@ -386,8 +484,6 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
                     float4 t = tot[slot]; // one path per slot, one shadow ray per path and bounce: no race
                     t.x = t.x + rad.x; t.y = t.y + rad.y; t.z = t.z + rad.z;
                     tot[slot] = t;
-                } else if (mode == RGK_SHADOW_CELL) {
-                    tot[slot] = make_float4(rad.x, rad.y, rad.z, 0.f); // `slot` = term cell, owned by this ray alone
                 } else { // RGK_SHADOW_SPLAT: light-tracing side effect, AddPixel(x2, y2, r, 0) tracer.cpp:20-26; `slot` = pixel
                     atomicAdd(&splat_rgb[3 * (size_t)slot + 0], rad.x);
                     atomicAdd(&splat_rgb[3 * (size_t)slot + 1], rad.y);
@@ -397,6 +493,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
             active = false;
         }
     }
+    if (JOB && lane == 0 && n_job_rays) atomicAdd(job_rays, n_job_rays); // shadow rays actually traced (the queue counts vertices)
     if (COUNT && util && lane == 0) {
         atomicAdd(&util[0], (unsigned long long)u_node_it); atomicAdd(&util[1], (unsigned long long)u_leaf_it);
         atomicAdd(&util[2], (unsigned long long)u_outer_it); atomicAdd(&util[3], (unsigned long long)u_refill);
@@ -447,6 +544,29 @@ __global__ __launch_bounds__(RGK_TRACE_BLOCK, (LDSN <= 16 ? RGK_TRACE_WAVES : 5)
     uint32_t n_nodes = 0, n_tris = 0;
     trace_persistent<true, COUNT, STACK, LDSN>(sc, shA, shB, shC, nullptr, nullptr, tot, vis_out, mode, splat_rgb, *count_ptr, fetch,
                                          lds_stack + threadIdx.x, ovf + (blockIdx.x * RGK_TRACE_BLOCK + threadIdx.x), gridDim.x * RGK_TRACE_BLOCK, n_nodes, n_tris);
+    if (COUNT) {
+        atomicAdd(&stats[2], (unsigned long long)n_nodes);
+        atomicAdd(&stats[3], (unsigned long long)n_tris);
+    }
+}
+
+// K5 for bidirectional rounds: one queue entry per camera-path vertex (JOB above).  jobs = {vertex}{contribution, mask}{emission},
+// rads = one radiance per ray; *rays_out receives the number of rays traced.
+#ifndef RGK_JOB_FINISH_ATOMIC
+#define RGK_JOB_FINISH_ATOMIC 0
+#endif
+#ifndef RGK_JOB_WAVES
+#define RGK_JOB_WAVES 6 // the vertex state costs ~12 VGPRs over a plain shadow ray: 8 waves per SIMD would spill 44 bytes
+#endif
+template <bool COUNT, int STACK, int LDSN>
+__global__ __launch_bounds__(RGK_TRACE_BLOCK, (LDSN <= 16 ? RGK_JOB_WAVES : 5)) void k_trace_shadow_jobs(const DevScene sc, const PassParams pp, const float4* __restrict__ jobs,
+                                                                   const float4* __restrict__ rads, float4* __restrict__ tot,
+                                                                   const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ fetch, uint32_t* __restrict__ rays_out,
+                                                                   unsigned long long* __restrict__ stats, int* __restrict__ ovf) {
+    __shared__ int lds_stack[LDSN * RGK_TRACE_BLOCK];
+    uint32_t n_nodes = 0, n_tris = 0;
+    trace_persistent<true, COUNT, STACK, LDSN, false, true>(sc, jobs, rads, nullptr, nullptr, nullptr, tot, nullptr, RGK_SHADOW_ADD, nullptr, *count_ptr, fetch,
+                                         lds_stack + threadIdx.x, ovf + (blockIdx.x * RGK_TRACE_BLOCK + threadIdx.x), gridDim.x * RGK_TRACE_BLOCK, n_nodes, n_tris, nullptr, &pp, nullptr, rays_out);
     if (COUNT) {
         atomicAdd(&stats[2], (unsigned long long)n_nodes);
         atomicAdd(&stats[3], (unsigned long long)n_tris);

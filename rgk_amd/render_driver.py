@@ -199,6 +199,7 @@ class RenderDriver:
         self.host_reduce = host_reduce  # gloo rehearsal: reduce through host copies instead of RCCL
         self.round_ob = None
         self.clock = time.time
+        self.checkpoint_tag = 0  # digest of scene + camera + parameters (rgk_accum_set_tag); 0: checkpoints are not compared
 
     def render_round(self, reduce=True):
         """One RenderRound: every rank renders its tiles into its private accumulator, then ONE sum-reduce of the RGB
@@ -247,6 +248,7 @@ class RenderDriver:
             a = np.ascontiguousarray(self.total_ob.data.cpu().numpy(), dtype=np.float32)
             c = np.ascontiguousarray(self.total_ob.count.cpu().numpy()).view(np.uint32)
             capi.check(lib, lib.rgk_accum_upload(acc, a.ctypes.data, c.ctypes.data))
+            capi.check(lib, lib.rgk_accum_set_tag(acc, self.checkpoint_tag))
             capi.check(lib, lib.rgk_accum_save(acc, str(path).encode(), self.rounds_done, self.seedcount))
         finally:
             lib.rgk_accum_destroy(acc)
@@ -259,6 +261,7 @@ class RenderDriver:
         capi.check(lib, lib.rgk_accum_create(self.cfg.xres, self.cfg.yres, self.scene.device, C.byref(acc)))
         try:
             rd_, sc_ = C.c_uint32(0), C.c_uint32(0)
+            capi.check(lib, lib.rgk_accum_set_tag(acc, self.checkpoint_tag))
             capi.check(lib, lib.rgk_accum_load(acc, str(path).encode(), C.byref(rd_), C.byref(sc_)))
             a = np.empty((self.cfg.yres, self.cfg.xres, 3), np.float32)
             c = np.empty((self.cfg.yres, self.cfg.xres), np.uint32)

@@ -2,8 +2,9 @@
 // RenderFrame -- holds a Scene, a Camera, a Config and an EXRTexture shaped like the reference's (reference_mirror.hpp),
 // binds them with the code INTEGRATION.md shows (rgk_binding.inc) and renders rounds.  A second mode drives the
 // multi-GPU entry points (device accumulator, tile sharding, RCCL reduce) the way one rank of an 8-GPU host would.
-//   caller <scene.bin> <out.bin> [--device-accum]
+//   caller <scene.bin> <out.bin> [--device-accum | --emulate-world W]
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 
@@ -33,8 +34,10 @@ static void fill_ltc(Reader& r, mat33* M, float* A) {
 }
 
 int main(int argc, char** argv) {
-    if (argc < 3) { fprintf(stderr, "usage: caller <scene.bin> <out.bin> [--device-accum]\n"); return 2; }
-    const bool device_accum = argc > 3 && !strcmp(argv[3], "--device-accum");
+    if (argc < 3) { fprintf(stderr, "usage: caller <scene.bin> <out.bin> [--device-accum | --emulate-world W]\n"); return 2; }
+    const int emulate_world = (argc > 4 && !strcmp(argv[3], "--emulate-world")) ? atoi(argv[4]) : 1;
+    if (emulate_world < 1 || emulate_world > 64) { fprintf(stderr, "--emulate-world: 1..64\n"); return 2; }
+    const bool device_accum = (argc > 3 && !strcmp(argv[3], "--device-accum")) || emulate_world > 1;
     try {
         Reader r(argv[1]);
         if (r.get<uint32_t>() != 0x524b4753u) throw std::runtime_error("bad magic");
@@ -159,28 +162,44 @@ int main(int argc, char** argv) {
         if (!device_accum) {
             for (unsigned int roundno = 0; roundno < cfg->render_rounds; roundno++) hip.RenderRound(cfg, camera, tasks, seedcount, seedstart, total_ob, rays_done);
         } else {
-            // one rank of a multi-GPU host: device accumulator, its share of the tiles, one RCCL reduce per round
-            rgk_accum* acc = nullptr;
+            // one rank of a multi-GPU host: a per-round device accumulator, the rank's share of the
+            // tiles, ONE RCCL reduce per round, the root adds the round's sum to its frame total.
+            // --emulate-world W: the W ranks of such a host one after the other on this one GPU, each with its own round
+            // accumulator, the in-place reduce replaced by what it computes (root += every other rank's buffer, the others keep
+            // theirs) -- the arithmetic of the pattern over several rounds, without needing W GPUs.
+            std::vector<rgk_accum*> round_acc((size_t)emulate_world, nullptr);
+            rgk_accum* total = nullptr;
             rgk_comm* comm = nullptr;
             uint8_t id[RGK_COMM_ID_BYTES];
-            const int rank = 0, world = 1;
-            if (rgk_accum_create(cfg->xres, cfg->yres, 0, &acc) != RGK_OK) throw std::runtime_error(rgk_last_error());
-            if (rgk_comm_get_unique_id(id) != RGK_OK || rgk_comm_create(id, rank, world, 0, &comm) != RGK_OK) throw std::runtime_error(rgk_last_error());
+            const int world = emulate_world;
+            for (auto& a : round_acc) if (rgk_accum_create(cfg->xres, cfg->yres, 0, &a) != RGK_OK) throw std::runtime_error(rgk_last_error());
+            if (rgk_accum_create(cfg->xres, cfg->yres, 0, &total) != RGK_OK) throw std::runtime_error(rgk_last_error());
+            if (world == 1 && (rgk_comm_get_unique_id(id) != RGK_OK || rgk_comm_create(id, 0, 1, 0, &comm) != RGK_OK)) throw std::runtime_error(rgk_last_error());
             rgk_params p = {cfg->xres, cfg->yres, cfg->multisample, cfg->recursion_level, cfg->clamp, cfg->russian, cfg->bumpmap_scale, 0u, cfg->reverse, RGK_SAMPLER_HALTON, 0u};
             for (unsigned int roundno = 0; roundno < cfg->render_rounds; roundno++) {
                 std::vector<rgk_tile> tiles(n_tiles), mine(n_tiles);
-                uint32_t n = n_tiles, n_mine = n_tiles;
+                uint32_t n = n_tiles;
                 if (rgk_generate_task_list(32, cfg->xres, cfg->yres, cfg->xres / 2.0f, cfg->yres / 2.0f, seedstart, seedcount, tiles.data(), &n) != RGK_OK) throw std::runtime_error(rgk_last_error());
                 seedcount += n;
-                if (rgk_shard_tiles(tiles.data(), n, rank, world, mine.data(), &n_mine) != RGK_OK) throw std::runtime_error(rgk_last_error());
-                rgk_counters cnt;
-                if (rgk_render_round_device(hip.scene, &rc, &p, mine.data(), n_mine, rgk_accum_rgb(acc), rgk_accum_count(acc), &cnt) != RGK_OK) throw std::runtime_error(rgk_last_error());
-                rays_done += cnt.path_rays;
-                if (rgk_accum_reduce(comm, rgk_accum_rgb(acc), rgk_accum_count(acc), cfg->xres, cfg->yres, 0) != RGK_OK) throw std::runtime_error(rgk_last_error());
+                for (int rank = 0; rank < world; rank++) {
+                    rgk_accum* acc = round_acc[(size_t)rank];
+                    uint32_t n_mine = n_tiles;
+                    if (rgk_shard_tiles(tiles.data(), n, rank, world, mine.data(), &n_mine) != RGK_OK) throw std::runtime_error(rgk_last_error());
+                    if (rgk_accum_clear(acc) != RGK_OK) throw std::runtime_error(rgk_last_error());
+                    rgk_counters cnt;
+                    if (rgk_render_round_device(hip.scene, &rc, &p, mine.data(), n_mine, rgk_accum_rgb(acc), rgk_accum_count(acc), &cnt) != RGK_OK) throw std::runtime_error(rgk_last_error());
+                    rays_done += cnt.path_rays;
+                }
+                if (comm) { // the real collective (one rank here: the sum of one buffer)
+                    if (rgk_accum_reduce(comm, rgk_accum_rgb(round_acc[0]), rgk_accum_count(round_acc[0]), cfg->xres, cfg->yres, 0) != RGK_OK) throw std::runtime_error(rgk_last_error());
+                } else      // what rgk_accum_reduce leaves behind: the root holds the sum, every other rank its own contribution
+                    for (int rank = 1; rank < world; rank++) if (rgk_accum_add(round_acc[0], round_acc[(size_t)rank]) != RGK_OK) throw std::runtime_error(rgk_last_error());
+                if (rgk_accum_add(total, round_acc[0]) != RGK_OK) throw std::runtime_error(rgk_last_error()); // root: total_ob.Accumulate(output_buffer)
             }
-            if (rgk_accum_download(acc, &total_ob.data[0].r, total_ob.count.data()) != RGK_OK) throw std::runtime_error(rgk_last_error());
+            if (rgk_accum_download(total, &total_ob.data[0].r, total_ob.count.data()) != RGK_OK) throw std::runtime_error(rgk_last_error());
             rgk_comm_destroy(comm);
-            rgk_accum_destroy(acc);
+            for (auto a : round_acc) rgk_accum_destroy(a);
+            rgk_accum_destroy(total);
         }
         std::ofstream o(argv[2], std::ios::binary);
         const uint64_t rd = rays_done;

@@ -112,3 +112,37 @@ def test_cpp_caller_equals_ctypes_path(tmp_path, mode):
         assert rays == ref_rays, name
         assert np.array_equal(acc.view(np.uint32), ref_acc.view(np.uint32)), f"{name}: C++ caller differs from the ctypes path"
         print(f"[cpp-caller {mode}] {name}: {prm.xres}x{prm.yres}x{prm.multisample} x {rounds} rounds, {rays} path rays, bit-identical")
+
+
+@pytest.mark.gpu
+def test_cpp_caller_multi_rank_rounds_sum_once(tmp_path):
+    """the multi-GPU pattern INTEGRATION.md section 3 documents (per-round accumulator -> in-place reduce -> the root adds
+    the round to its total) must count every rank's every round exactly once.  The earlier form reduced an accumulator that
+    kept growing, which adds the other ranks' round-1 data again in round 2 -- invisible with one rank.  Here the caller plays
+    2 and 3 ranks on one GPU over 3 rounds, with the reduce replaced by what it computes (root += the others, the others keep
+    theirs): bit-identical to the single-process frame, because tiles are disjoint and the per-pixel additions are the same."""
+    from rgk_amd import render_driver as rd
+    exe = build_caller(tmp_path)
+    wl = Workload("cornell-256", scale=0.25, spp=4)
+    prm, rounds = wl.params(), 3
+    scene_bin = str(tmp_path / "c.bin")
+    dump_scene(scene_bin, wl.builder, wl.camera, prm, rounds)
+    sc = rd.Scene(wl.builder.to_desc(), device=0)
+    ref_acc = np.zeros((prm.yres, prm.xres, 3), np.float32)
+    ref_cnt = np.zeros((prm.yres, prm.xres), np.uint32)
+    ref_rays, seedcount = 0, 0
+    for _ in range(rounds):
+        tiles = rd.generate_task_list(prm.xres, prm.yres, rd.SEEDSTART, seedcount)
+        seedcount += len(tiles)
+        ref_acc, ref_cnt, c = sc.render_round(wl.camera, prm, tiles, ref_acc, ref_cnt)
+        ref_rays += c.path_rays
+    sc.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for world in (2, 3):
+        out_bin = str(tmp_path / f"c{world}.out")
+        r = subprocess.run([exe, scene_bin, out_bin, "--emulate-world", str(world)], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr + r.stdout
+        acc, cnt, rays = read_result(out_bin, prm.xres, prm.yres)
+        assert np.array_equal(cnt, ref_cnt), f"world {world}: sample counts differ (a round counted twice?)"
+        assert rays == ref_rays
+        assert np.array_equal(acc.view(np.uint32), ref_acc.view(np.uint32)), f"world {world}: frame differs from the single-process one"

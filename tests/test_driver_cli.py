@@ -94,6 +94,33 @@ def test_cli_renders_writes_resumes_and_claims_frames(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_compare_suffix_and_per_frame_checkpoints(tmp_path):
+    """-c (src/main.cpp:129-131,196) and the checkpoint rules of ADVICE r2: with -r every frame has its own checkpoint (a
+    finished frame's checkpoint says "all rounds done", so sharing one file left every later frame empty), and a checkpoint
+    written for another camera / scene / parameter set is refused instead of being continued."""
+    from rgk_amd import render_driver as rd
+    cfg = tmp_path / "s.json"
+    cfg.write_text(SCENE)
+    r = run_cli([str(cfg), "-D", str(tmp_path), "-c", "-p", "-q"], str(tmp_path))
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert os.path.exists(str(tmp_path / "cli.preview.cmp.exr")) and not os.path.exists(str(tmp_path / "cli.exr"))
+    ck = str(tmp_path / "rot.ck")
+    r = run_cli([str(cfg), "-D", str(tmp_path), "-r", "--frames", "2", "--checkpoint", ck, "-q"], str(tmp_path))
+    assert r.returncode == 0, r.stderr + r.stdout
+    f0, f1 = rd.read_exr(str(tmp_path / "cli.00000.exr")), rd.read_exr(str(tmp_path / "cli.00001.exr"))
+    assert f0[..., :3].max() == 1.0 and f1[..., :3].max() == 1.0 and not np.array_equal(f0, f1)   # BOTH frames were rendered
+    assert os.path.exists(str(tmp_path / "rot.00000.ck")) and os.path.exists(str(tmp_path / "rot.00001.ck")) and not os.path.exists(ck)
+    # frame 1's checkpoint offered to frame 0's camera: refused, nothing rendered on top of it
+    os.replace(str(tmp_path / "rot.00001.ck"), str(tmp_path / "one.ck"))
+    r = run_cli([str(cfg), "-D", str(tmp_path), "--checkpoint", str(tmp_path / "one.ck")], str(tmp_path))
+    assert r.returncode == 1 and "cannot resume" in r.stdout and "different scene, camera or parameter set" in r.stdout, r.stdout + r.stderr
+    # ... while frame 0's own is accepted by the same camera
+    os.replace(str(tmp_path / "rot.00000.ck"), str(tmp_path / "zero.ck"))
+    r = run_cli([str(cfg), "-D", str(tmp_path), "--checkpoint", str(tmp_path / "zero.ck")], str(tmp_path))
+    assert r.returncode == 0 and "Resumed from" in r.stdout and "3 rounds done" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
 def test_progress_is_fed_from_the_device(tmp_path):
     """rgk_scene_get_progress from a second thread while a round runs: stages only grow, end at stages == total, rounds count."""
     import threading

@@ -643,6 +643,54 @@ def test_round_properties_sponza4_config5_full_size(rd, oracle):
     assert rel <= 1e-3 and gate >= 0.999 and strict >= 0.99
 
 
+def test_round_properties_dragon_sponza_config4_full_size(rd, oracle):
+    """BASELINE configs[3] at its full 1920x1080x512 spp, reverse 3, depth 40 on the 1.05 M-triangle scene (proxy atrium + statue
+    stand-in, the geometry the bench line runs): a whole bidirectional round -- counts, range, the two-halves tile deal -- and the
+    oracle on 8 tiles of the same frame at the full 512 spp.  Splats (light-tracing side effects, tracer.cpp:20-26) are float
+    atomics on the GPU: their order varies from run to run, so sums that include them agree to float re-association (measured
+    ~1e-7 relative), not bit for bit; everything a path adds to its own pixel keeps the oracle's order."""
+    from rgk_amd.workloads import Workload
+    wl = Workload("dragon-sponza-1080p")
+    assert (wl.xres, wl.yres, wl.multisample, wl.depth, wl.reverse) == (1920, 1080, 512, 40, 3)
+    wl.builder.finalize()
+    assert len(wl.builder.F) > 1000000
+    g = rd.Scene(wl.builder.to_desc())
+    prm = wl.params()
+    tiles = rd.generate_task_list(wl.xres, wl.yres)
+    assert len(tiles) == 2040
+    acc, cnt, k = g.render_round(wl.camera, prm, tiles)
+    assert (cnt == 512).all() and k.paths == 1920 * 1080 * 512          # splats add radiance with count 0
+    assert np.isfinite(acc).all() and (acc >= 0).all()
+    assert k.path_rays >= k.paths and k.shadow_rays > 0
+    # the multi-GPU deal (tile i -> rank i mod 2): the halves add up to the whole; their splats land anywhere in the frame
+    a2 = np.zeros_like(acc); c2 = np.zeros_like(cnt)
+    ev = (capi.Tile * ((len(tiles) + 1) // 2))(*tiles[0::2]); od = (capi.Tile * (len(tiles) // 2))(*tiles[1::2])
+    _, _, k_ev = g.render_round(wl.camera, prm, ev, a2, c2); _, _, k_od = g.render_round(wl.camera, prm, od, a2, c2)
+    assert np.array_equal(cnt, c2) and k_ev.path_rays + k_od.path_rays == k.path_rays and k_ev.shadow_rays + k_od.shadow_rays == k.shadow_rays
+    rel_halves = float(np.linalg.norm(acc - a2) / np.linalg.norm(acc))
+    assert rel_halves <= 1e-5, rel_halves
+    # the oracle on every 255th tile of the centre-out list, the GPU on the same 8 tiles alone (a tile's light sub-paths splat
+    # into other tiles: both sides must trace the same set of paths for the frames to be comparable)
+    sub = (capi.Tile * 8)(*tiles[0::255])
+    ag = np.zeros_like(acc); cg = np.zeros_like(cnt); _, _, kg = g.render_round(wl.camera, prm, sub, ag, cg)
+    o = oracle.OracleScene(wl.builder.to_desc())
+    ao = np.zeros_like(acc); co = np.zeros_like(cnt); _, _, ko = o.render_round(wl.camera, prm, sub, ao, co)
+    assert np.array_equal(cg, co) and (co > 0).sum() == 8 * 1024
+    assert abs(int(kg.path_rays) - int(ko.path_rays)) <= 1e-4 * ko.path_rays
+    # the reference tests Visibility first and evaluates the BxDFs after (path_tracer.cpp:431,466); the kernels evaluate first and
+    # do not trace a ray that could only carry zero radiance: fewer shadow rays, the same sums
+    assert 0.5 * ko.shadow_rays <= kg.shadow_rays <= ko.shadow_rays
+    m = co > 0
+    rel = float(np.linalg.norm(ag - ao) / np.linalg.norm(ao))
+    rel_tiles = float(np.linalg.norm(ag[m] - ao[m]) / np.linalg.norm(ao[m]))
+    d = np.linalg.norm(ag - ao, axis=2)[m]; r = np.linalg.norm(ao, axis=2)[m]
+    strict = float((d <= np.maximum(1e-3 * r, 1e-6)).mean())
+    gate = float((d <= np.maximum(1e-3 * r, 4.0 * wl.clamp)).mean())    # SURVEY 8(d): max(1e-3 |ref|, 4 clamp / S) on the per-sample mean
+    record_parity("test_round_properties_dragon_sponza_config4_full_size", rel_l2_frame=rel, rel_l2_8_tiles=rel_tiles, within_1e3_strict=strict,
+                  within_survey_gate=gate, halves_vs_whole=rel_halves, bit_identical=float((d == 0).mean()), size="1920x1080x512 reverse 3")
+    assert rel <= 1e-3 and rel_tiles <= 1e-3 and gate >= 0.999, (rel, rel_tiles, gate, strict)
+
+
 def test_edge_cases(rd, oracle, cornell):
     g, o = both(rd, oracle, cornell)
     prm = cornell.params()

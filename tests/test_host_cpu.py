@@ -475,6 +475,35 @@ def test_reverse_splats_reduce_is_a_true_sum_world_size_4(oracle):
     assert np.array_equal(data, data2) and np.array_equal(count, count2)
 
 
+def test_bench_launches_its_own_ranks_when_started_plainly():
+    """`python bench.py --gpus N` is how the driver starts the scaling run: with no launcher around it (WORLD_SIZE unset)
+    bench.py itself starts one child per GPU before touching the GPU, gives each what torch.distributed.run would have
+    (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_*), passes the arguments on unchanged, prints rank 0's line alone on stdout and fails if
+    any rank does.  RGK_BENCH_ECHO_ENV makes a rank report its environment and stop before it needs a GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["RGK_BENCH_ECHO_ENV"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    out = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(out) == 1 and out[0]["RANK"] == "0"          # ONE JSON line on stdout: rank 0's
+    others = [json.loads(ln) for ln in r.stderr.splitlines() if ln.startswith("{")]
+    ranks = sorted(int(o["RANK"]) for o in out + others)
+    assert ranks == [0, 1, 2, 3]
+    for o in out + others:
+        assert o["WORLD_SIZE"] == "4" and o["LOCAL_RANK"] == o["RANK"] and o["MASTER_ADDR"] == "127.0.0.1"
+        assert o["MASTER_PORT"] == out[0]["MASTER_PORT"] and int(o["MASTER_PORT"]) > 0
+        assert o["argv"] == ["--gpus", "4", "--steps", "2", "--warmup", "1"]
+    env["RGK_BENCH_ECHO_FAIL_RANK"] = "2"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "rank(s) failed" in r.stderr
+    # under a launcher (WORLD_SIZE set) bench.py is a rank, not a launcher
+    env.pop("RGK_BENCH_ECHO_FAIL_RANK")
+    env.update({"WORLD_SIZE": "2", "RANK": "1", "LOCAL_RANK": "1"})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and json.loads(r.stdout)["RANK"] == "1"
+
+
 # ----------------------------------------------------------------------- output path (SURVEY 8(f) f3)
 def test_float_to_half_is_round_to_nearest_even(product_lib):
     rng = np.random.default_rng(5)
