@@ -122,6 +122,8 @@ def main():
     ap.add_argument("--emulate-shard", type=int, default=0, help="diagnostic: ONE rank's share of a K-GPU strong-scaled round (tiles i %% K == 0) on this GPU, no reduce; not a benchmark number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--textures", choices=["u8", "f32"], default="u8", help="f32: hand every image texture over as floats, as a binding to the "
+                    "reference does (FileTexture keeps only decoded floats); the core then stores those with <= 256 distinct values as bytes itself")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + RGK_FORCE_DEVICE=0 rehearses N ranks on one GPU")
     args = ap.parse_args()
 
@@ -162,6 +164,11 @@ def main():
     base_spp = wl.multisample
     if args.scaling == "weak" and world > 1:
         wl.multisample = base_spp * world
+    if args.textures == "f32":
+        for t in wl.builder.textures:
+            if t["kind"] == capi.TEX_RGB8:
+                t["data"] = np.ascontiguousarray(t["lut"][t["data"]], dtype=np.float32)
+                t["kind"], t["lut"] = capi.TEX_RGB32F, None
     scene = rd.Scene(wl.builder.to_desc(), device=local_rank)
     info = scene.info()
 
@@ -325,6 +332,7 @@ def main():
         "config": {"workload": f"{args.workload} {wl.xres}x{wl.yres}x{wl.multisample}spp depth {wl.depth} russian {wl.russian:.2f}, {args.scaling} scaling"
                                + ("" if args.scale == 1.0 and args.spp is None else " (REDUCED SIZE: not the benchmark number)"),
                    "geometry": wl.geometry, "triangles": int(len(wl.builder.F)), "sampler": "halton-cp",
+                   "textures": f"handed over as {args.textures}; {info.n_palettized_textures} of {info.n_float_textures} float textures stored as bytes + value table",
                    "tiles": drv.n_tasks, "parallelism": f"tiles round-robin over {world} GPU(s) + one RCCL reduce per round"},
         "mrays_per_s_path": round(path_rays / elapsed / 1e6, 2),
         "mrays_per_s_all": round((path_rays + shadow_rays) / elapsed / 1e6, 2),

@@ -66,7 +66,9 @@ typedef struct rgk_material {
 typedef enum rgk_texture_kind {
     RGK_TEX_SOLID = 0,  /* SolidTexture: constant colour, slopes 0 */
     RGK_TEX_RGB32F = 1, /* FileTexture: width*height Color{r,g,b} float triples, row-major,
-                           already gamma-decoded / flipped as the reference loader does */
+                           already gamma-decoded / flipped as the reference loader does -- what a binding to the reference hands
+                           over (FileTexture::data).  One whose channels take <= 256 distinct values (every texture the reference
+                           decodes from an 8-bit file, src/texture.cpp:203,252-254) is stored like RGK_TEX_RGB8 internally */
     RGK_TEX_RGB8 = 2    /* FileTexture decoded from an 8-bit file (PNG/JPEG, src/texture.cpp:189-292):
                            the bytes as stored (row-major, flipped as the loader does) plus the 256-entry
                            table that turns a byte into the float the reference would hold
@@ -138,6 +140,9 @@ typedef struct rgk_scene_desc {
 } rgk_scene_desc;
 
 #define RGK_BUILD_HOST_SAH 0u /* binned-SAH on the host, collapsed to the 4-wide quantised BVH (default: best traversal)        */
+#define RGK_BUILD_KEEP_FLOAT_TEXTURES 2u /* store every RGK_TEX_RGB32F texture as float4 texels, even one with <= 256 distinct channel
+                                            values (by default such a texture is stored as bytes + the table of its values: the same
+                                            texel values, a quarter of the traffic)                                                */
 #define RGK_BUILD_DEVICE 1u   /* LBVH on the GPU (Morton sort, Karras hierarchy, refit, collapse + quantisation: all on the device):
                                  milliseconds instead of a second at 1 M triangles, more node visits per ray                  */
 
@@ -214,6 +219,8 @@ typedef struct rgk_scene_info {
     uint32_t tri_bytes;   /* s_tri                                */
     uint32_t max_depth;
     uint32_t n_leaf_refs;
+    uint32_t n_float_textures;      /* RGK_TEX_RGB32F textures handed over ...                                          */
+    uint32_t n_palettized_textures; /* ... and how many of them are stored as bytes + value table (<= 256 distinct values) */
 } rgk_scene_info;
 
 typedef struct rgk_hit {
@@ -245,6 +252,14 @@ int rgk_scene_get_info(const rgk_scene *scene, rgk_scene_info *out);
 
 /* Callable from ANY thread while another thread is inside rgk_render_round*: never blocks, touches no device state. */
 int rgk_scene_get_progress(const rgk_scene *scene, rgk_progress *out);
+
+/* Tuning switches of ONE scene; none of them changes a result (the tests render with each and compare bits).  Keys:
+ * "entry_points", "entry_cap", "light_entry" (0 / 1: where camera rays and first shadow rays start their walk), "sample_group"
+ * (log2 of the samples of a pixel that sit side by side in the path-slot order, 0..6; -1: default), "batch_paths" (paths per
+ * pass; 0: sized from the free memory), "workspace_gb" (0: default).  Their initial values are read from the environment
+ * (RGK_ENTRY_POINTS, RGK_ENTRY_CAP, RGK_LIGHT_ENTRY, RGK_SAMPLE_GROUP, RGK_BATCH_PATHS, RGK_WORKSPACE_GB) ONCE, in
+ * rgk_scene_create; a round never reads the environment.  Not while a round is in flight on this scene. */
+int rgk_scene_set_tuning(rgk_scene *scene, const char *key, double value);
 
 /* GenerateTaskList, src/render_driver.cpp:30-46.  Tiles of tile_size, sorted by
  * distance of the tile midpoint to (mid_x, mid_y); ties broken by (y0, x0)

@@ -46,37 +46,56 @@ __device__ __forceinline__ float4* lv_ptr(const PassParams& pp, uint32_t k, uint
 }
 
 // ---- light ray, path_tracer.cpp:336-349,359-363
-__global__ __launch_bounds__(256) void k_raygen_light(const DevScene sc, const DevCamera cam, const PassParams pp, float4* __restrict__ rayA,
-                                                       float4* __restrict__ rayB, float4* __restrict__ thr) {
+// A light ray that cannot touch the scene's box can never make a light vertex, and with a light far outside the geometry
+// that is most of them (configs[3]: nine in ten): only the others are queued (same clip, same decision as the traversal
+// kernel's own, rgk_trace.h clip_to_scene) -- the first traversal launch, the hit list and the ray records shrink accordingly.
+// The reference counts every light ray it traces (raycount++, :126); the host adds the culled ones back (RGK_CNT_CULLED).
+__global__ __launch_bounds__(RGK_SHADE_BLOCK) void k_raygen_light(const DevScene sc, const DevCamera cam, const PassParams pp, float4* __restrict__ rayA,
+                                                                   float4* __restrict__ rayB, float4* __restrict__ thr, uint32_t* __restrict__ counters) {
     const uint32_t n = pp.npix * pp.ns;
     const SamplerTab tb = {pp.htab, pp.multisample};
-    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n; slot += gridDim.x * blockDim.x) {
-        uint32_t srel, j; slot_decode(pp, slot, j, srel);
-        const uint32_t seed = pp.pix_seed[pp.j0 + j], s = pp.s0 + srel;
-        const uint32_t base2d = (cam.lens_size != 0.0f) ? 2u : 1u;
-        const float2 areal_s = sample2d_t(tb, seed, s, base2d), lightdir_s = sample2d_t(tb, seed, s, base2d + 1u);
-        f3 lpos;
-        const uint32_t lcode = light_code(sc, sample2d_t(tb, seed, s, base2d + 2u), sample1d_t(tb, seed, s, 0u), areal_s, lpos);
-        pp.light[slot] = make_float4(lpos.x, lpos.y, lpos.z, __uint_as_float(lcode));
-        DLight L = light_from_code(sc, lpos, lcode);
-        f3 normal = L.normal, ldir = mk3(0.f, 1.f, 0.f);
-        if (L.type == 0) {
-            const f3 dir = sphere_uniform(areal_s);
-            normal = (L.size > 0.0f) ? dir : mk3(0.f, 0.f, 0.f); // Q15 (defined)
-            ldir = qrot(rotation_from_y(norm3(dir)), hemisphere_cosine_y(lightdir_s));
-        } else if (L.type == 1) {
-            ldir = qrot(rotation_from_y(L.normal), hemisphere_cosine_y(lightdir_s));
+    __shared__ uint32_t s_cnt[RGK_SHADE_BLOCK / 64];
+    __shared__ uint32_t s_base;
+    for (uint32_t base = blockIdx.x * RGK_SHADE_BLOCK; base < n; base += gridDim.x * RGK_SHADE_BLOCK) {
+        const uint32_t slot = base + threadIdx.x;
+        bool queue = false;
+        float4 a = make_float4(0, 0, 0, 0), b = a, li = a, ls = a;
+        if (slot < n) {
+            uint32_t srel, j; slot_decode(pp, slot, j, srel);
+            const uint32_t seed = pp.pix_seed[pp.j0 + j], s = pp.s0 + srel;
+            const uint32_t base2d = (cam.lens_size != 0.0f) ? 2u : 1u;
+            const float2 areal_s = sample2d_t(tb, seed, s, base2d), lightdir_s = sample2d_t(tb, seed, s, base2d + 1u);
+            f3 lpos;
+            const uint32_t lcode = light_code(sc, sample2d_t(tb, seed, s, base2d + 2u), sample1d_t(tb, seed, s, 0u), areal_s, lpos);
+            li = make_float4(lpos.x, lpos.y, lpos.z, __uint_as_float(lcode));
+            DLight L = light_from_code(sc, lpos, lcode);
+            f3 normal = L.normal, ldir = mk3(0.f, 1.f, 0.f);
+            if (L.type == 0) {
+                const f3 dir = sphere_uniform(areal_s);
+                normal = (L.size > 0.0f) ? dir : mk3(0.f, 0.f, 0.f); // Q15 (defined)
+                ldir = qrot(rotation_from_y(norm3(dir)), hemisphere_cosine_y(lightdir_s));
+            } else if (L.type == 1) {
+                ldir = qrot(rotation_from_y(L.normal), hemisphere_cosine_y(lightdir_s));
+            }
+            L.normal = normal;
+            const f3 o = lpos + sc.epsilon * normal * 100.0f;
+            const f3 d = norm3(ldir);
+            const float k = (L.type < 0) ? 0.0f : L.intensity * light_dir_factor(L, ldir);
+            const f3 start = L.color * mk3(k, k, k);
+            ls = make_float4(start.x, start.y, start.z, 0.f);
+            a = make_float4(o.x, o.y, o.z, d.x);
+            b = make_float4(d.y, d.z, __uint_as_float(0xffffffffu), __uint_as_float(slot));
+            pp.lvmask[slot] = 0u; // no light vertex yet
+            const bool nan_ray = (o.x != o.x) | (o.y != o.y) | (o.z != o.z) | (d.x != d.x) | (d.y != d.y) | (d.z != d.z);
+            float t0, t1;
+            queue = !nan_ray && clip_to_scene(sc, o, d, 0.0f, 10000.0f, t0, t1); // Ray::near / Ray::far defaults, src/ray.hpp:25-26
         }
-        L.normal = normal;
-        const f3 o = lpos + sc.epsilon * normal * 100.0f;
-        const f3 d = norm3(ldir);
-        const float k = (L.type < 0) ? 0.0f : L.intensity * light_dir_factor(L, ldir);
-        const f3 start = L.color * mk3(k, k, k);
-        pp.lstart[slot] = make_float4(start.x, start.y, start.z, 0.f);
-        rayA[slot] = make_float4(o.x, o.y, o.z, d.x);
-        rayB[slot] = make_float4(d.y, d.z, __uint_as_float(0xffffffffu), __uint_as_float(slot));
-        thr[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(1u << 16));
-        pp.lvmask[slot] = 0u; // no light vertex yet
+        const uint32_t p = block_append(queue, &counters[RGK_CNT_QUEUE], s_cnt, &s_base);
+        if (queue) {
+            rayA[p] = a; rayB[p] = b;
+            pp.light[slot] = li; pp.lstart[slot] = ls;
+            thr[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(1u << 16));
+        }
     }
 }
 
@@ -235,10 +254,11 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade_light(const DevSce
 // radiance of ray q (q = 0 NEE, q = 1..reverse the light vertices) for the bits q of mask.  A ray whose radiance is exactly
 // zero is not traced (it could only add zero).
 __global__ __launch_bounds__(256) void k_connect(const DevScene sc, const PassParams pp, const uint32_t bounce, float4* __restrict__ jobs,
-                                                  float4* __restrict__ rads, const uint32_t* __restrict__ counters) {
+                                                  float4* __restrict__ rads, uint32_t* __restrict__ counters) {
     const uint32_t count = counters[RGK_CNT_CONN + bounce];
     lut_lds_fill(sc);
     const size_t bs = pp.batch;
+    uint32_t n_rays = 0; // shadow rays this thread queued (counters[RGK_CNT_SRAYS + bounce]: the queue itself counts vertices)
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += gridDim.x * blockDim.x) {
         const uint32_t i = pp.connlist[t];
         const float4 c0 = pp.conn[i], c1 = pp.conn[bs + i], c2 = pp.conn[2 * bs + i], c3 = pp.conn[3 * bs + i], c4 = pp.conn[4 * bs + i], c5 = pp.conn[5 * bs + i];
@@ -289,5 +309,8 @@ __global__ __launch_bounds__(256) void k_connect(const DevScene sc, const PassPa
         }
         jobs[t] = c0;
         jobs[bs + t] = make_float4(c4.x, c4.y, c4.z, __uint_as_float(mask));
+        n_rays += (uint32_t)__popc(mask & 0xffu);
     }
+    for (int ofs = 32; ofs > 0; ofs >>= 1) n_rays += __shfl_xor(n_rays, ofs);
+    if ((threadIdx.x & 63) == 0 && n_rays) atomicAdd(&counters[RGK_CNT_SRAYS + bounce], n_rays);
 }

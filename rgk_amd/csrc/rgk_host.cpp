@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <iterator>
 #include <atomic>
 #include <cmath>
 #include <cstdarg>
@@ -457,8 +458,23 @@ struct DevBuf {
 
 extern "C" __attribute__((visibility("hidden"))) int rgk_internal_fail(int code, const char* msg) { return fail(code, "%s", msg); }
 
+// Tuning switches of one scene (nothing here changes a result).  Filled ONCE, in rgk_scene_create, from the environment
+// (RGK_ENTRY_POINTS, RGK_ENTRY_CAP, RGK_LIGHT_ENTRY, RGK_SAMPLE_GROUP, RGK_BATCH_PATHS, RGK_WORKSPACE_GB, RGK_DEBUG_BVH,
+// RGK_DEBUG_UTIL); afterwards only rgk_scene_set_tuning changes them -- a round never reads the environment (round 2 did, per
+// round: process-global state under a host that may render from two threads).
+struct RgkTuning {
+    bool entry_points = true; // camera rays start at their pixel group's entry nodes (k_entry_points)
+    bool entry_cap = true;    // ... capped behind the group's first hits from a frame's second round on
+    bool light_entry = true;  // first-vertex shadow rays of a single-light scene start at light-side entry nodes
+    int sample_group = -1;    // log2 of the samples of a pixel side by side in the slot order; -1: the compiled default
+    size_t batch_paths = 0;   // paths per pass; 0: sized from the memory that is free
+    double workspace_gb = 0;  // ... or from this many GB; 0: 96 (160 for bidirectional rounds), at most 60 % of what is free
+    bool debug_bvh = false, debug_util = false;
+};
+
 struct rgk_scene {
     int device = 0;
+    RgkTuning tune;
     hipStream_t stream = nullptr;
     rgk_scene_info info{};
     DevScene dev{};
@@ -736,6 +752,15 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
     s->device = device;
     struct Guard { rgk_scene* s; ~Guard() { delete s; } } guard{s};
     HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    {
+        auto off = [](const char* name) { const char* e = std::getenv(name); return e && e[0] == '0'; };
+        RgkTuning& t = s->tune;
+        t.entry_points = !off("RGK_ENTRY_POINTS"); t.entry_cap = !off("RGK_ENTRY_CAP"); t.light_entry = !off("RGK_LIGHT_ENTRY");
+        if (const char* e = std::getenv("RGK_SAMPLE_GROUP")) t.sample_group = std::min(6, std::max(0, std::atoi(e)));
+        if (const char* e = std::getenv("RGK_BATCH_PATHS")) t.batch_paths = std::max<size_t>(1024, strtoull(e, nullptr, 10));
+        if (const char* e = std::getenv("RGK_WORKSPACE_GB")) t.workspace_gb = atof(e);
+        t.debug_bvh = std::getenv("RGK_DEBUG_BVH") != nullptr; t.debug_util = std::getenv("RGK_DEBUG_UTIL") != nullptr;
+    }
 
     const uint32_t nt = d->n_triangles;
     auto vert = [&](uint32_t i) { return V3{d->vertices[3 * i], d->vertices[3 * i + 1], d->vertices[3 * i + 2]}; };
@@ -887,33 +912,105 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
         for (int k = 0; k < 6; k++) t.q[k][3] = uvs[k]; // uvA.x uvA.y uvB.x uvB.y uvC.x uvC.y
         t.mat = d->tri_material[i];
     }
-    // textures: image texels into one float4 pool; a TexRef per (material, slot)
+    // textures: image texels into one float4 pool (float textures) or one dword pool + byte -> float tables (8-bit ones);
+    // a TexRef per (material, slot)
     std::vector<float4> pool;
     std::vector<uint32_t> pool8;
     std::vector<float> luts;
     std::vector<TexRef> trefs(d->n_textures);
+    // A float texture whose channel values are at most 256 distinct floats is what a loader leaves that decodes an 8-bit
+    // file to floats and keeps only those (the reference: Color(byte / 255).gammaDecode(2.2) per channel,
+    // src/texture.cpp:203,252-254, every FileTexture it holds).  Such a texture is stored as bytes + the table of its values --
+    // bit-identical by construction (the table holds the very floats), a quarter of the texel traffic, and the table sits in LDS.
+    // Textures share a table while the union of their value sets fits 256 entries (one table for all of Sponza's 17 images).
+    struct Palette { std::vector<uint32_t> vals; bool fixed; uint32_t lut_off; }; // sorted bit patterns; fixed: a caller-supplied table
+    std::vector<Palette> palettes;
+    std::vector<int> tex_palette(d->n_textures, -1);
+    uint32_t n_float_tex = 0, n_palettized = 0;
+    auto bits_of = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+    for (uint32_t i = 0; i < d->n_textures; i++) { // caller-supplied tables first: a float texture whose values all occur in one shares it
+        const rgk_texture& t = d->textures[i];
+        if (t.kind != RGK_TEX_RGB8) continue;
+        bool have = false;
+        for (const Palette& p : palettes) if (std::memcmp(&luts[p.lut_off], t.lut, 256 * sizeof(float)) == 0) { have = true; break; }
+        if (have) continue;
+        Palette p; p.fixed = true; p.lut_off = (uint32_t)luts.size();
+        luts.insert(luts.end(), t.lut, t.lut + 256);
+        for (int k = 0; k < 256; k++) p.vals.push_back(bits_of(t.lut[k]));
+        std::sort(p.vals.begin(), p.vals.end());
+        p.vals.erase(std::unique(p.vals.begin(), p.vals.end()), p.vals.end());
+        palettes.push_back(std::move(p));
+    }
+    if (!(d->build_flags & RGK_BUILD_KEEP_FLOAT_TEXTURES))
+        for (uint32_t i = 0; i < d->n_textures; i++) {
+            const rgk_texture& t = d->textures[i];
+            if (t.kind != RGK_TEX_RGB32F || t.width > 65535 || t.height > 65535) continue;
+            // distinct channel values, giving up at the 257th (open addressing, 1024 slots)
+            std::vector<uint32_t> slots(1024, 0u);
+            std::vector<uint8_t> used(1024, 0);
+            std::vector<uint32_t> vals;
+            const size_t n = (size_t)3 * t.width * t.height;
+            bool ok = true;
+            for (size_t k = 0; k < n && ok; k++) {
+                const uint32_t u = bits_of(t.texels[k]);
+                uint32_t h = (u * 2654435761u) >> 22;
+                while (used[h] && slots[h] != u) h = (h + 1) & 1023u;
+                if (!used[h]) { used[h] = 1; slots[h] = u; vals.push_back(u); if (vals.size() > 256) ok = false; }
+            }
+            if (!ok) continue;
+            std::sort(vals.begin(), vals.end());
+            int pick = -1;
+            for (size_t p = 0; p < palettes.size() && pick < 0; p++) // all of it already in a table?
+                if (std::includes(palettes[p].vals.begin(), palettes[p].vals.end(), vals.begin(), vals.end())) pick = (int)p;
+            for (size_t p = 0; p < palettes.size() && pick < 0; p++) { // a table of this scene's that can take the new values?
+                if (palettes[p].fixed) continue;
+                std::vector<uint32_t> u;
+                std::set_union(palettes[p].vals.begin(), palettes[p].vals.end(), vals.begin(), vals.end(), std::back_inserter(u));
+                if (u.size() <= 256) { palettes[p].vals.swap(u); pick = (int)p; }
+            }
+            if (pick < 0) { Palette p; p.fixed = false; p.lut_off = 0; p.vals = vals; palettes.push_back(std::move(p)); pick = (int)palettes.size() - 1; }
+            tex_palette[i] = pick;
+        }
+    for (Palette& p : palettes) // this scene's own tables: the sorted values, padded with zeros
+        if (!p.fixed) {
+            p.lut_off = (uint32_t)luts.size();
+            for (size_t k = 0; k < 256; k++) { float f = 0.f; if (k < p.vals.size()) std::memcpy(&f, &p.vals[k], 4); luts.push_back(f); }
+        }
     for (uint32_t i = 0; i < d->n_textures; i++) {
         const rgk_texture& t = d->textures[i];
         TexRef& o = trefs[i];
         o.kind = t.kind; o.a = o.b = o.c = 0;
         if (t.kind == RGK_TEX_SOLID) {
             std::memcpy(&o.a, &t.color[0], 4); std::memcpy(&o.b, &t.color[1], 4); std::memcpy(&o.c, &t.color[2], 4);
-        } else if (t.kind == RGK_TEX_RGB8) {
+        } else if (t.kind == RGK_TEX_RGB8 || tex_palette[i] >= 0) {
             if (t.width > 65535 || t.height > 65535) return fail(RGK_ERR_UNSUPPORTED, "texture %u larger than 65535 texels on a side", i);
             const size_t n = (size_t)t.width * t.height;
             if (pool8.size() + n >= (1ull << 30)) return fail(RGK_ERR_UNSUPPORTED, "8-bit texel pool exceeds 2^30 texels"); // 32-bit byte offsets
+            o.kind = RGK_TEX_RGB8;
             o.a = t.width | (t.height << 16);
             o.b = (uint32_t)pool8.size();
-            o.c = 0;
-            for (size_t k = 0; k + 256 <= luts.size(); k += 256) // share identical tables
-                if (std::memcmp(&luts[k], t.lut, 256 * sizeof(float)) == 0) { o.c = (uint32_t)k; goto have_lut; }
-            o.c = (uint32_t)luts.size();
-            luts.insert(luts.end(), t.lut, t.lut + 256);
-        have_lut:
             pool8.reserve(pool8.size() + n);
-            for (size_t k = 0; k < n; k++)
-                pool8.push_back((uint32_t)t.texels8[3 * k] | ((uint32_t)t.texels8[3 * k + 1] << 8) | ((uint32_t)t.texels8[3 * k + 2] << 16));
+            if (t.kind == RGK_TEX_RGB8) {
+                for (const Palette& p : palettes) if (p.fixed && std::memcmp(&luts[p.lut_off], t.lut, 256 * sizeof(float)) == 0) { o.c = p.lut_off; break; }
+                for (size_t k = 0; k < n; k++)
+                    pool8.push_back((uint32_t)t.texels8[3 * k] | ((uint32_t)t.texels8[3 * k + 1] << 8) | ((uint32_t)t.texels8[3 * k + 2] << 16));
+            } else { // a float texture with few distinct values: its texels as indices into the table (the first entry holding the value)
+                n_float_tex++; n_palettized++;
+                const Palette& p = palettes[(size_t)tex_palette[i]];
+                o.c = p.lut_off;
+                std::vector<std::pair<uint32_t, uint8_t>> idx; // (bit pattern, table index), sorted by pattern
+                for (int k = 255; k >= 0; k--) idx.push_back({bits_of(luts[p.lut_off + (size_t)k]), (uint8_t)k});
+                std::stable_sort(idx.begin(), idx.end(), [](const std::pair<uint32_t, uint8_t>& a, const std::pair<uint32_t, uint8_t>& b) { return a.first < b.first || (a.first == b.first && a.second < b.second); });
+                auto index_of = [&](float f) -> uint32_t {
+                    const uint32_t u = bits_of(f);
+                    auto it = std::lower_bound(idx.begin(), idx.end(), std::make_pair(u, (uint8_t)0));
+                    return it->second; // present by construction
+                };
+                for (size_t k = 0; k < n; k++)
+                    pool8.push_back(index_of(t.texels[3 * k]) | (index_of(t.texels[3 * k + 1]) << 8) | (index_of(t.texels[3 * k + 2]) << 16));
+            }
         } else {
+            n_float_tex++;
             if (t.width > 65535 || t.height > 65535) return fail(RGK_ERR_UNSUPPORTED, "texture %u larger than 65535 texels on a side", i);
             const size_t n = (size_t)t.width * t.height;
             if (pool.size() + n >= (1ull << 28)) return fail(RGK_ERR_UNSUPPORTED, "float texel pool exceeds 2^28 texels"); // 32-bit byte offsets
@@ -1008,7 +1105,7 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
     }
     ds.nodes = s->nodes.p;
     { const char* e = std::getenv("RGK_WALK_Q"); ds.walk_q = e ? (uint32_t)std::atoi(e) : 3u; }
-    if (std::getenv("RGK_DEBUG_BVH")) std::fprintf(stderr, "[rgk] bvh4 (%s) nodes %u max_stack %u max_depth %u refs %u of %u triangles\n", on_device ? "device LBVH" : "host SAH", n_nodes, max_stack, max_depth, n_refs, nt);
+    if (s->tune.debug_bvh) std::fprintf(stderr, "[rgk] bvh4 (%s) nodes %u max_stack %u max_depth %u refs %u of %u triangles\n", on_device ? "device LBVH" : "host SAH", n_nodes, max_stack, max_depth, n_refs, nt);
     ds.tris = s->tris.p; ds.tri_shade = s->tri_shade.p;
     ds.materials = s->materials.p; ds.texels = s->texels.p; ds.texels8 = s->texels8.p; ds.luts = s->luts.p; ds.n_lut_floats = (uint32_t)luts.size(); ds.n_materials = (uint32_t)mats.size();
     ds.pointlights = s->pointlights.p; ds.areal = s->areal.p; ds.areal_tris = s->areal_tris.p;
@@ -1029,6 +1126,7 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
     inf.total_areal_power = total_areal; inf.total_point_power = total_point;
     inf.n_nodes = n_nodes; inf.node_bytes = RGK_NODE_BYTES; inf.tri_bytes = RGK_TRI_BYTES;
     inf.max_depth = max_depth; inf.n_leaf_refs = n_refs;
+    inf.n_float_textures = n_float_tex; inf.n_palettized_textures = n_palettized;
     guard.s = nullptr;
     *out = s;
     return RGK_OK;
@@ -1047,6 +1145,23 @@ int rgk_scene_get_progress(const rgk_scene* s, rgk_progress* out) {
     out->stage = s->h_stage ? *(volatile const uint32_t*)s->h_stage : 0u; out->stages = s->prog_stages.load(); out->rounds = s->prog_rounds.load(); out->busy = s->prog_busy.load();
     out->round_pixels = s->prog_pixels.load(); out->round_paths = s->prog_paths.load();
     if (out->stage > out->stages) out->stage = out->stages;
+    return RGK_OK;
+}
+
+int rgk_scene_set_tuning(rgk_scene* s, const char* key, double value) {
+    if (!s || !key) return fail(RGK_ERR_INVALID, "null argument");
+    if (s->prog_busy.load()) return fail(RGK_ERR_INVALID, "rgk_scene_set_tuning while a round is in flight on this scene");
+    RgkTuning& t = s->tune;
+    const std::string k(key);
+    if (k == "entry_points") t.entry_points = value != 0;
+    else if (k == "entry_cap") t.entry_cap = value != 0;
+    else if (k == "light_entry") t.light_entry = value != 0;
+    else if (k == "sample_group") t.sample_group = value < 0 ? -1 : (int)std::min(6.0, value);
+    else if (k == "batch_paths") t.batch_paths = value <= 0 ? 0 : std::max<size_t>(1024, (size_t)value);
+    else if (k == "workspace_gb") t.workspace_gb = value <= 0 ? 0.0 : value;
+    else return fail(RGK_ERR_INVALID, "unknown tuning key '%s'", key);
+    // per-frame lists were made under the old switches: the next round rebuilds them
+    s->entry_key = 0; s->entry_n = 0; s->entry_capped = 0; s->lentry_done = 0;
     return RGK_OK;
 }
 
@@ -1107,13 +1222,13 @@ static void make_camera(const rgk_camera* c, DevCamera& o) { // the members Rend
 // 96 GB of the 288 GB HBM3E (measured on Sponza 1080p x 256 spp: 2^25 paths/pass 2235 Mpaths/s, 2^27 2398,
 // 2^28 2440 -- fewer, longer launches and shorter tails; 48 -> 96 GB: +1.4 % there, +6 % on the bidirectional
 // configuration whose paths carry 3.5x the state).  RGK_WORKSPACE_GB / RGK_BATCH_PATHS override.
-static size_t batch_paths(uint32_t reverse) {
-    if (const char* e = getenv("RGK_BATCH_PATHS")) return std::max<size_t>(1024, strtoull(e, nullptr, 10));
+static size_t batch_paths(const RgkTuning& tune, uint32_t reverse) {
+    if (tune.batch_paths) return tune.batch_paths;
     // rays 2 x 32, hit 16, state 16, sum 16, light 16, shadow queue 48, generic list 4; bidirectional: + light start 16, light
     // vertices, hit list 4, and the vertex queue's 2 + (1 + reverse) more float4 than a ray's 3
     const size_t per_path = 180 + (reverse ? 16 + 16 * RGK_LV_FLOAT4 * (size_t)reverse + 12 + 16 * (6 + 4 + (size_t)reverse + 1) : 0);
-    const char* g = getenv("RGK_WORKSPACE_GB");
-    double gb = g ? atof(g) : (reverse ? 160.0 : 96.0); // bidirectional paths carry 3.5x the state: 765 -> 781 Mpaths/s
+    const bool g = tune.workspace_gb > 0;
+    double gb = g ? tune.workspace_gb : (reverse ? 160.0 : 96.0); // bidirectional paths carry 3.5x the state: 765 -> 781 Mpaths/s
     if (!g) { // a shared or smaller card: never plan for more than 60 % of what is free right now
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) gb = std::min(gb, 0.6 * (double)free_b / 1e9);
@@ -1152,8 +1267,7 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
         HIPCHK(hipMemcpyAsync(s->tile_buf.p, tiles, (size_t)n_tiles * sizeof(rgk_tile), hipMemcpyHostToDevice, st0));
         HIPCHK(hipMemcpyAsync(s->tile_buf.p + (size_t)n_tiles * 5, toff.data(), (n_tiles + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st0));
         rgk_launch_build_pixel_list(st0, reinterpret_cast<const rgk_tile*>(s->tile_buf.p), s->tile_buf.p + (size_t)n_tiles * 5, n_tiles, s->pix_xy.p, s->pix_seed.p);
-        const char* ee = std::getenv("RGK_ENTRY_POINTS"); // 0: every camera ray starts at the root
-        if (!(ee && ee[0] == '0')) {
+        if (s->tune.entry_points) { // (off: every camera ray starts at the root)
             // the entry nodes depend on the camera and on which pixels the list holds in which order -- not on the seeds: a frame's
             // rounds share them (0.7 ms per round at 1080p otherwise)
             uint64_t key = 1469598103934665603ull;
@@ -1174,8 +1288,8 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
     // no light at all: TracePath builds no light sub-path (`reverse > 0 && valid light`), same as reverse == 0
     const uint32_t R = (s->dev.total_point_power + s->dev.total_areal_power > 0.0f) ? prm->reverse : 0u;
     // paths per pass: what the card has room for now (an existing workspace counts as room); halved on an allocation failure
-    size_t B = batch_paths(R);
-    if (s->batch_reverse >= R) B = std::max(B, s->batch);
+    size_t B = batch_paths(s->tune, R);
+    if (!s->tune.batch_paths && s->batch_reverse >= R) B = std::max(B, s->batch); // (an explicit batch size is taken literally)
     size_t npix_pass;
     uint32_t ns_pass;
     for (;;) {
@@ -1240,12 +1354,10 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
     pp.pix_xy = s->pix_xy.p; pp.pix_seed = s->pix_seed.p;
     pp.entry = s->entry.p; // (null when switched off; only the unidirectional bounce-0 launch reads it)
     pp.entry_cap = s->entry_cap.p;
-    bool cap_entries = s->entry.p != nullptr;
-    { const char* ce = std::getenv("RGK_ENTRY_CAP"); if (ce && ce[0] == '0') cap_entries = false; }
+    const bool cap_entries = s->entry.p != nullptr && s->tune.entry_cap;
     pp.lentry = nullptr;
     // one point / sphere light and nothing else that emits: every first-vertex shadow ray starts there (k_entry_points_light)
-    bool light_entry = s->entry.p && s->dev.n_pointlights == 1 && s->dev.n_areal == 0;
-    { const char* le = std::getenv("RGK_LIGHT_ENTRY"); if (le && le[0] == '0') light_entry = false; }
+    const bool light_entry = s->entry.p && s->tune.light_entry && s->dev.n_pointlights == 1 && s->dev.n_areal == 0;
     if (light_entry) {
         const size_t groups = ((size_t)P + RGK_ENTRY_PIX - 1) / RGK_ENTRY_PIX + 1;
         if ((rc = s->lentry.alloc(groups * RGK_ENTRY_K)) || (rc = s->trange.alloc(groups * 2)) || (rc = s->lbox.alloc(groups * 2))) return rc;
@@ -1283,8 +1395,7 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
             pp.s0 = s0;
             pp.ns = std::min(ns_pass, prm->multisample - s0);
             {   // 2^gshift samples of a pixel side by side in the slot order (rgk_kernels.h PassParams); RGK_SAMPLE_GROUP = log2
-                const char* e = std::getenv("RGK_SAMPLE_GROUP");
-                uint32_t g = e ? (uint32_t)std::min(6, std::max(0, std::atoi(e))) : (uint32_t)RGK_SAMPLE_GROUP_DEFAULT;
+                uint32_t g = s->tune.sample_group >= 0 ? (uint32_t)s->tune.sample_group : (uint32_t)RGK_SAMPLE_GROUP_DEFAULT;
                 while (g && (pp.ns & ((1u << g) - 1u))) g--;
                 pp.gshift = g;
             }
@@ -1294,8 +1405,8 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
             if (R > 0) {
                 // light sub-path first (its sampler dimensions are fixed), splats straight into the accumulator
                 rgk_launch_set_bound(n0, n0);
-                TIMED(3, rgk_launch_init_counters(st, cl, n0));
-                TIMED(3, rgk_launch_raygen_light(st, s->dev, cam, pp, s->rayA[0].p, s->rayB[0].p, s->thr.p));
+                TIMED(3, rgk_launch_init_counters(st, cl, 0u)); // (k_raygen_light queues the light rays that can touch the scene's box)
+                TIMED(3, rgk_launch_raygen_light(st, s->dev, cam, pp, s->rayA[0].p, s->rayB[0].p, s->thr.p, cl));
                 for (uint32_t k = 0; k < R; k++) {
                     int q = k & 1;
                     TIMED(0, rgk_launch_trace_closest(st, s->dev, s->tcfg, count_stats, s->rayA[q].p, s->rayB[q].p, nullptr, s->hit.p,
@@ -1336,7 +1447,7 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
                         if ((size_t)pp.j0 + pp.npix > s->lentry_done) {
                             TIMED(3, rgk_launch_light_entry_points(st, s->dev, cam, pp, (uint32_t)P, s->trange.p, s->lentry.p, s->lbox.p));
                             s->lentry_done = (size_t)pp.j0 + pp.npix;
-                            if (std::getenv("RGK_DEBUG_BVH")) { // how many pixel groups got light-side entry nodes below the root
+                            if (s->tune.debug_bvh) { // how many pixel groups got light-side entry nodes below the root
                                 const size_t g0 = pp.j0 >> RGK_ENTRY_SHIFT, g1 = ((size_t)pp.j0 + pp.npix + RGK_ENTRY_PIX - 1) >> RGK_ENTRY_SHIFT;
                                 std::vector<int> he((g1 - g0) * RGK_ENTRY_K);
                                 HIPCHK(hipStreamSynchronize(st));
@@ -1358,7 +1469,7 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
                                                          RGK_SHADOW_ADD, nullptr, cn + RGK_CNT_SHADOW + b, cn + RGK_CNT_FETCH_S + b, s->stats.p));
                     if (R > 0) // (after the plain rays: both add into the slot sums, a slot has a vertex in ONE of the two queues)
                         TIMED(1, rgk_launch_trace_shadow_jobs(st, s->dev, pp, s->tcfg, count_stats, s->jobs.p, s->rads.p, s->tot.p,
-                                                              cn + RGK_CNT_CONN + b, cn + RGK_CNT_FETCH_J + b, cn + RGK_CNT_SRAYS + b, s->stats.p));
+                                                              cn + RGK_CNT_CONN + b, cn + RGK_CNT_FETCH_J + b, s->stats.p));
                     if ((rc = stage_mark(stage_target + b + 1))) return rc;
                     if (track && b >= 3 && (b & 1) && b + 1 < prm->depth && (rc = queue_len(cn + RGK_CNT_QUEUE + b + 1, ub))) return rc;
                 }
@@ -1369,7 +1480,8 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
             HIPCHK(hipMemcpyAsync(s->h_counters, s->counters.p, 2 * RGK_CNT_TOTAL * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
             for (uint32_t b = 0; b < prm->depth; b++) { path_rays += s->h_counters[RGK_CNT_QUEUE + b]; shadow_rays += s->h_counters[RGK_CNT_SHADOW + b] + s->h_counters[RGK_CNT_SRAYS + b]; }
-            for (uint32_t k = 0; k < R; k++) { path_rays += s->h_counters[RGK_CNT_TOTAL + RGK_CNT_QUEUE + k]; shadow_rays += s->h_counters[RGK_CNT_TOTAL + RGK_CNT_SHADOW + k]; }
+            // (light rays: the reference traces and counts one per path, path_tracer.cpp:126,349 -- the ones culled before the queue included)
+            for (uint32_t k = 0; k < R; k++) { path_rays += k == 0 ? n0 : s->h_counters[RGK_CNT_TOTAL + RGK_CNT_QUEUE + k]; shadow_rays += s->h_counters[RGK_CNT_TOTAL + RGK_CNT_SHADOW + k]; }
         }
     }
     HIPCHK(hipGetLastError());
@@ -1459,7 +1571,7 @@ int rgk_trace_closest(rgk_scene* s, uint32_t n, const float* rays, const int32_t
         unsigned long long h[8];
         HIPCHK(hipMemcpy(h, s->stats.p, sizeof(h), hipMemcpyDeviceToHost));
         counters->node_visits = h[0]; counters->tri_tests = h[1]; counters->path_rays = n;
-        if (std::getenv("RGK_DEBUG_UTIL")) // lane occupancy per phase of the walker: lane-visits / (64 x wave iterations)
+        if (s->tune.debug_util) // lane occupancy per phase of the walker: lane-visits / (64 x wave iterations)
             std::fprintf(stderr, "[rgk util] rays %u  node visits %llu in %llu wave iterations (%.3f of lanes)  triangle tests %llu in %llu (%.3f)  outer iterations %llu  refills %llu\n",
                          n, h[0], h[4], h[4] ? (double)h[0] / (64.0 * (double)h[4]) : 0.0, h[1], h[5], h[5] ? (double)h[1] / (64.0 * (double)h[5]) : 0.0, h[6], h[7]);
         float ms = 0.f;

@@ -105,14 +105,14 @@ void rgk_launch_trace_shadow(hipStream_t st, const DevScene& sc, const RgkTraceC
 void rgk_launch_trace_shadow_first(hipStream_t st, const DevScene& sc, const PassParams& pp, const RgkTraceCfg& tc, bool count_stats, const float4* shA, const float4* shB,
                                    const float4* shC, float4* tot, const uint32_t* count_ptr, uint32_t* fetch, unsigned long long* stats);
 void rgk_launch_raygen_light(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, float4* rayA, float4* rayB,
-                             float4* thr);
+                             float4* thr, uint32_t* counters);
 void rgk_launch_shade_light(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t k, const float4* rayA,
                             const float4* rayB, const float4* hit, float4* thr, float4* nextA, float4* nextB, float4* shA, float4* shB,
                             float4* shC, uint32_t* counters);
 void rgk_launch_list_hits(hipStream_t st, const float4* hit, const uint32_t* count_ptr, uint32_t* list, uint32_t* list_count);
-void rgk_launch_connect(hipStream_t st, const DevScene& sc, const PassParams& pp, uint32_t bounce, float4* jobs, float4* rads, const uint32_t* counters);
+void rgk_launch_connect(hipStream_t st, const DevScene& sc, const PassParams& pp, uint32_t bounce, float4* jobs, float4* rads, uint32_t* counters);
 void rgk_launch_trace_shadow_jobs(hipStream_t st, const DevScene& sc, const PassParams& pp, const RgkTraceCfg& tc, bool count_stats, const float4* jobs, const float4* rads,
-                                  float4* tot, const uint32_t* count_ptr, uint32_t* fetch, uint32_t* rays_out, unsigned long long* stats);
+                                  float4* tot, const uint32_t* count_ptr, uint32_t* fetch, unsigned long long* stats);
 void rgk_launch_shade(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t bounce, const float4* rayA,
                       const float4* rayB, const float4* hit, float4* thr, float4* tot, float4* nextA, float4* nextB, float4* shA,
                       float4* shB, float4* shC, uint32_t* counters, bool bdpt = false);

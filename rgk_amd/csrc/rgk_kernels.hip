@@ -260,8 +260,9 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, RGK_SHADE_WAVES) void k_shade(cons
                         nA = make_float4(no.x, no.y, no.z, nd.x);
                         nB = make_float4(nd.y, nd.z, __int_as_float(tri), __uint_as_float(slot));
                         thr[slot] = make_float4(cum.x, cum.y, cum.z, __uint_as_float((n & 0xffffu) | (c1 << 16)));
-                        if (FIRST) pp.light[slot] = li_keep;
                     }
+                    // the path's light: later vertices read it (and k_connect, for the NEE ray of a vertex on the record route)
+                    if (FIRST && (go || conn)) pp.light[slot] = li_keep;
                 }
                 } // !defer
             }
@@ -875,8 +876,9 @@ static inline int slot_grid(const PassParams& pp) {
     return grid > 256 * 16 ? 256 * 16 : grid;
 }
 void rgk_launch_raygen_light(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, float4* rayA, float4* rayB,
-                             float4* thr) {
-    k_raygen_light<<<slot_grid(pp), 256, 0, st>>>(sc, cam, pp, rayA, rayB, thr);
+                             float4* thr, uint32_t* counters) {
+    const uint32_t n = pp.npix * pp.ns;
+    k_raygen_light<<<bounded_grid(256 * 4 * 512 / RGK_SHADE_BLOCK, n, RGK_SHADE_BLOCK), RGK_SHADE_BLOCK, 0, st>>>(sc, cam, pp, rayA, rayB, thr, counters);
 }
 void rgk_launch_shade_light(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t k, const float4* rayA,
                             const float4* rayB, const float4* hit, float4* thr, float4* nextA, float4* nextB, float4* shA, float4* shB,
@@ -884,13 +886,13 @@ void rgk_launch_shade_light(hipStream_t st, const DevScene& sc, const DevCamera&
     k_shade_light<false><<<bounded_grid(256 * 4 * 512 / RGK_SHADE_BLOCK, g_bound, RGK_SHADE_BLOCK), RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, k, rayA, rayB, hit, thr, nextA, nextB, shA, shB, shC, counters);
     k_shade_light<true><<<bounded_grid(256 * 2 * 512 / RGK_SHADE_BLOCK, g_bound, RGK_SHADE_BLOCK), RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, k, rayA, rayB, hit, thr, nextA, nextB, shA, shB, shC, counters);
 }
-void rgk_launch_connect(hipStream_t st, const DevScene& sc, const PassParams& pp, uint32_t bounce, float4* jobs, float4* rads, const uint32_t* counters) {
+void rgk_launch_connect(hipStream_t st, const DevScene& sc, const PassParams& pp, uint32_t bounce, float4* jobs, float4* rads, uint32_t* counters) {
     k_connect<<<bounded_grid(256 * 8, g_bound, 256), 256, RGK_LDS_SHADE_BYTES, st>>>(sc, pp, bounce, jobs, rads, counters);
 }
 void rgk_launch_list_hits(hipStream_t st, const float4* hit, const uint32_t* count_ptr, uint32_t* list, uint32_t* list_count) {
     k_list_hits<<<bounded_grid(256 * 4 * 512 / RGK_SHADE_BLOCK, g_bound, RGK_SHADE_BLOCK), RGK_SHADE_BLOCK, 0, st>>>(hit, count_ptr, list, list_count);
 }
 void rgk_launch_trace_shadow_jobs(hipStream_t st, const DevScene& sc, const PassParams& pp, const RgkTraceCfg& tc, bool count_stats, const float4* jobs, const float4* rads,
-                                  float4* tot, const uint32_t* count_ptr, uint32_t* fetch, uint32_t* rays_out, unsigned long long* stats) {
-    RGK_TRACE_DISPATCH(k_trace_shadow_jobs, g_bound_shadow, sc, pp, jobs, rads, tot, count_ptr, fetch, rays_out, stats, tc.ovf)
+                                  float4* tot, const uint32_t* count_ptr, uint32_t* fetch, unsigned long long* stats) {
+    RGK_TRACE_DISPATCH(k_trace_shadow_jobs, g_bound_shadow, sc, pp, jobs, rads, tot, count_ptr, fetch, stats, tc.ovf)
 }

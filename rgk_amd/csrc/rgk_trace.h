@@ -152,7 +152,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
                                                  const int mode, float* __restrict__ splat_rgb,
                                                  const uint32_t count, uint32_t* __restrict__ fetch, int* __restrict__ stack, int* __restrict__ ovf, const uint32_t ostride,
                                                  uint32_t& n_nodes, uint32_t& n_tris, const DevCamera* cam = nullptr, const PassParams* pp = nullptr,
-                                                 unsigned long long* __restrict__ util = nullptr, uint32_t* __restrict__ job_rays = nullptr) {
+                                                 unsigned long long* __restrict__ util = nullptr) {
     const int lane = threadIdx.x & 63;
     uint32_t u_node_it = 0, u_leaf_it = 0, u_outer_it = 0, u_refill = 0; // COUNT: wave-level iteration counts (lane occupancy per phase)
     const int stride = RGK_TRACE_BLOCK;
@@ -171,7 +171,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
     int best_tri = -1, cur = STACK_SENTINEL, sp = 0;
     // JOB: the sum over the vertex's visible rays so far, the rays still to trace (mask bits 0..7; bit 8: emissive)
     f3 jsum = o;
-    uint32_t jmask = 0, n_job_rays = 0;
+    uint32_t jmask = 0;
     bool seg_pending = false;
 
 #define RGK_PUT(x) { if (LDSN >= STACK || sp < LDSN) stack[sp * stride] = (x); else ovf[(size_t)(sp - LDSN) * ostride] = (x); }
@@ -230,7 +230,6 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
                         seg_pending = true; active = true;
                         if (jmask & 1u) {
                             jmask &= ~1u;
-                            n_job_rays += (uint32_t)__popcll(__ballot(true)); // wave-uniform: the lanes starting a ray here
                             rad = mk3(r0.x, r0.y, r0.z);
                             RGK_JOB_RAY(mk3(f0.x, f0.y, f0.z), mk3(a.x, a.y, a.z))
                         }
@@ -332,7 +331,6 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
                 }
                 const uint32_t q = (uint32_t)__builtin_ctz(m);
                 jmask &= ~(1u << q);
-                n_job_rays += (uint32_t)__popcll(__ballot(true));
                 const float4 r = q1[(size_t)q * pp->batch + idx];
                 rad = mk3(r.x, r.y, r.z);
                 const float4 fr = (q == 0u) ? q0[3 * (size_t)pp->batch + idx] : pp->lv[(size_t)((q - 1u) * RGK_LV_FLOAT4) * pp->batch + jslot];
@@ -493,7 +491,6 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
             active = false;
         }
     }
-    if (JOB && lane == 0 && n_job_rays) atomicAdd(job_rays, n_job_rays); // shadow rays actually traced (the queue counts vertices)
     if (COUNT && util && lane == 0) {
         atomicAdd(&util[0], (unsigned long long)u_node_it); atomicAdd(&util[1], (unsigned long long)u_leaf_it);
         atomicAdd(&util[2], (unsigned long long)u_outer_it); atomicAdd(&util[3], (unsigned long long)u_refill);
@@ -551,7 +548,7 @@ __global__ __launch_bounds__(RGK_TRACE_BLOCK, (LDSN <= 16 ? RGK_TRACE_WAVES : 5)
 }
 
 // K5 for bidirectional rounds: one queue entry per camera-path vertex (JOB above).  jobs = {vertex}{contribution, mask}{emission},
-// rads = one radiance per ray; *rays_out receives the number of rays traced.
+// rads = one radiance per ray (k_connect wrote both, and counted the rays).
 #ifndef RGK_JOB_FINISH_ATOMIC
 #define RGK_JOB_FINISH_ATOMIC 0
 #endif
@@ -561,12 +558,12 @@ __global__ __launch_bounds__(RGK_TRACE_BLOCK, (LDSN <= 16 ? RGK_TRACE_WAVES : 5)
 template <bool COUNT, int STACK, int LDSN>
 __global__ __launch_bounds__(RGK_TRACE_BLOCK, (LDSN <= 16 ? RGK_JOB_WAVES : 5)) void k_trace_shadow_jobs(const DevScene sc, const PassParams pp, const float4* __restrict__ jobs,
                                                                    const float4* __restrict__ rads, float4* __restrict__ tot,
-                                                                   const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ fetch, uint32_t* __restrict__ rays_out,
+                                                                   const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ fetch,
                                                                    unsigned long long* __restrict__ stats, int* __restrict__ ovf) {
     __shared__ int lds_stack[LDSN * RGK_TRACE_BLOCK];
     uint32_t n_nodes = 0, n_tris = 0;
     trace_persistent<true, COUNT, STACK, LDSN, false, true>(sc, jobs, rads, nullptr, nullptr, nullptr, tot, nullptr, RGK_SHADOW_ADD, nullptr, *count_ptr, fetch,
-                                         lds_stack + threadIdx.x, ovf + (blockIdx.x * RGK_TRACE_BLOCK + threadIdx.x), gridDim.x * RGK_TRACE_BLOCK, n_nodes, n_tris, nullptr, &pp, nullptr, rays_out);
+                                         lds_stack + threadIdx.x, ovf + (blockIdx.x * RGK_TRACE_BLOCK + threadIdx.x), gridDim.x * RGK_TRACE_BLOCK, n_nodes, n_tris, nullptr, &pp);
     if (COUNT) {
         atomicAdd(&stats[2], (unsigned long long)n_nodes);
         atomicAdd(&stats[3], (unsigned long long)n_tris);

@@ -64,6 +64,13 @@ class Scene:
 
     __del__ = close
 
+    def set_tuning(self, **kw):
+        """rgk_scene_set_tuning: per-scene tuning switches (entry_points, entry_cap, light_entry, sample_group, batch_paths,
+        workspace_gb); none changes a result."""
+        for k, v in kw.items():
+            capi.check(self.lib, self.lib.rgk_scene_set_tuning(self.h, k.encode(), float(v)))
+        return self
+
     def info(self):
         i = capi.SceneInfo()
         capi.check(self.lib, self.lib.rgk_scene_get_info(self.h, C.byref(i)))

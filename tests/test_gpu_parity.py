@@ -243,13 +243,8 @@ def test_slot_order_does_not_change_the_image(rd, oracle):
         tiles = rd.generate_task_list(wl.xres, wl.yres)
         imgs = {}
         for grp, batch in (("0", None), ("2", None), ("3", None), ("6", None), ("3", 20000)):
-            os.environ["RGK_SAMPLE_GROUP"] = grp
-            if batch: os.environ["RGK_BATCH_PATHS"] = str(batch)
-            try:
-                imgs[(grp, batch)], cnt, _ = g.render_round(wl.camera, wl.params(), tiles)
-            finally:
-                del os.environ["RGK_SAMPLE_GROUP"]
-                os.environ.pop("RGK_BATCH_PATHS", None)
+            g.set_tuning(sample_group=int(grp), batch_paths=batch or 0)     # per-scene switches (rgk_scene_set_tuning): no environment involved
+            imgs[(grp, batch)], cnt, _ = g.render_round(wl.camera, wl.params(), tiles)
             assert (cnt == spp).all()
         base = imgs[("0", None)]
         assert all(np.array_equal(base, v) for v in imgs.values()), spp
@@ -272,29 +267,19 @@ def test_entry_nodes_do_not_change_the_image(rd):
         g = rd.Scene(wl.builder.to_desc())
         tiles = rd.generate_task_list(wl.xres, wl.yres)
         imgs = []
-        for cam_entry, cap, light_entry in (("0", "0", "0"), ("1", "0", "0"), ("1", "1", "0"), ("1", "1", "1")):
-            os.environ["RGK_ENTRY_POINTS"], os.environ["RGK_ENTRY_CAP"], os.environ["RGK_LIGHT_ENTRY"] = cam_entry, cap, light_entry
-            try:
-                gg = rd.Scene(wl.builder.to_desc())        # (a fresh scene per variant: nothing cached from the previous one)
-                acc, cnt, k = gg.render_round(wl.camera, wl.params(), tiles)
-                acc2, _, k2 = gg.render_round(wl.camera, wl.params(), tiles)   # second round of the frame: lists capped behind the first hits
-            finally:
-                del os.environ["RGK_ENTRY_POINTS"], os.environ["RGK_ENTRY_CAP"], os.environ["RGK_LIGHT_ENTRY"]
+        for cam_entry, cap, light_entry in ((0, 0, 0), (1, 0, 0), (1, 1, 0), (1, 1, 1)):
+            gg = rd.Scene(wl.builder.to_desc()).set_tuning(entry_points=cam_entry, entry_cap=cap, light_entry=light_entry)  # (a fresh scene per variant: nothing cached from the previous one)
+            acc, cnt, k = gg.render_round(wl.camera, wl.params(), tiles)
+            acc2, _, k2 = gg.render_round(wl.camera, wl.params(), tiles)   # second round of the frame: lists capped behind the first hits
             assert np.array_equal(acc, acc2) and k.path_rays == k2.path_rays and k.shadow_rays == k2.shadow_rays, (name, kw, cam_entry, cap, light_entry)
             imgs.append((acc, k.path_rays, k.shadow_rays))
         for acc, pr, sr in imgs[1:]:
             assert np.array_equal(acc, imgs[0][0]) and pr == imgs[0][1] and sr == imgs[0][2], (name, kw)
         # other slot orders (a wave then mixes pixel groups: the per-lane path of k_group_trange) and passes split over pixels and samples
         for grp, batch in (("0", None), ("6", None), ("3", 30000)):
-            os.environ["RGK_SAMPLE_GROUP"] = grp
-            if batch: os.environ["RGK_BATCH_PATHS"] = str(batch)
-            try:
-                g2 = rd.Scene(wl.builder.to_desc())     # (a fresh scene: nothing cached from the runs above)
-                acc, cnt, k = g2.render_round(wl.camera, wl.params(), tiles)
-                acc2, _, _ = g2.render_round(wl.camera, wl.params(), tiles)      # second round of the frame: cached entry nodes
-            finally:
-                del os.environ["RGK_SAMPLE_GROUP"]
-                os.environ.pop("RGK_BATCH_PATHS", None)
+            g2 = rd.Scene(wl.builder.to_desc()).set_tuning(sample_group=int(grp), batch_paths=batch or 0)     # (a fresh scene: nothing cached from the runs above)
+            acc, cnt, k = g2.render_round(wl.camera, wl.params(), tiles)
+            acc2, _, _ = g2.render_round(wl.camera, wl.params(), tiles)      # second round of the frame: cached entry nodes
             assert np.array_equal(acc, imgs[0][0]) and np.array_equal(acc2, imgs[0][0]), (name, kw, grp, batch)
 
 
@@ -552,11 +537,9 @@ def test_round_properties_cornell_config2_size(rd, oracle):
     g.render_round(wl.camera, prm, ev, a3, c3); g.render_round(wl.camera, prm, od, a3, c3)
     assert np.array_equal(acc, a3) and np.array_equal(cnt, c3)
     # small batches (many passes over pixels and samples) change nothing
-    os.environ["RGK_BATCH_PATHS"] = str(300000)
-    try:
-        a4, c4, _ = g.render_round(wl.camera, prm, tiles)
-    finally:
-        del os.environ["RGK_BATCH_PATHS"]
+    g.set_tuning(batch_paths=300000)
+    a4, c4, _ = g.render_round(wl.camera, prm, tiles)
+    g.set_tuning(batch_paths=0)
     assert np.array_equal(acc, a4)
     # linearity of the accumulator: a second round adds
     tiles_b = rd.generate_task_list(wl.xres, wl.yres, seedcount_base=len(tiles))
@@ -1017,3 +1000,73 @@ def test_device_built_bvh_gives_the_same_hits(rd, oracle):
         record_parity("test_device_built_bvh_gives_the_same_hits:" + name + ":image", rel_l2=rel, bit_identical=float((np.abs(ah - ad).max(axis=2) == 0).mean()))
         assert rel <= 5e-3
         gh.close(); gd.close()
+
+
+# ----------------------------------------------------------------------- textures as a reference host hands them over
+def _textures_as_float(sb):
+    """What tests/cpp/rgk_binding.inc hands over: every FileTexture as RGK_TEX_RGB32F (the reference keeps only the decoded
+    floats, src/texture.cpp:203,252-254)."""
+    n = 0
+    for t in sb.textures:
+        if t["kind"] == capi.TEX_RGB8:
+            t["data"] = np.ascontiguousarray(t["lut"][t["data"]], dtype=np.float32)
+            t["kind"], t["lut"] = capi.TEX_RGB32F, None
+            n += 1
+    return n
+
+
+def test_float_textures_with_few_values_take_the_byte_path(rd):
+    """the headline ran on 8-bit textures (bytes + byte -> float table), a format the reference-side binding
+    cannot deliver -- it has floats only.  rgk_scene_create now recognises a float texture whose channels take <= 256 distinct
+    values and stores it as bytes + the table of those very floats: the same texel values (so the same image, bit for bit, as
+    with RGK_TEX_RGB8 input and as with float4 storage), at the 8-bit path's cost.  A texture with more values stays float."""
+    from rgk_amd.workloads import SceneFixture, Workload
+    for name, mk in (("sponza-proxy", lambda: Workload("sponza-1080p", scale=0.1, spp=8)),
+                     ("rubiks-bump", lambda: SceneFixture(os.path.join(ROOT, "tests", "golden", "scene_rubiks-bump.npz"), scale=0.1, spp=4, depth=4))):
+        a, b = mk(), mk()
+        n_conv = _textures_as_float(b.builder)
+        assert n_conv >= 1
+        prm = a.params()
+        tiles = rd.generate_task_list(prm.xres, prm.yres)
+        ga = rd.Scene(a.builder.to_desc())
+        gb = rd.Scene(b.builder.to_desc())
+        b.builder.build_flags = capi.BUILD_KEEP_FLOAT_TEXTURES
+        gc = rd.Scene(b.builder.to_desc())
+        b.builder.build_flags = capi.BUILD_HOST_SAH
+        ia, ib, ic = ga.info(), gb.info(), gc.info()
+        assert (ia.n_float_textures, ia.n_palettized_textures) == (0, 0)
+        assert ib.n_float_textures == n_conv and ib.n_palettized_textures == n_conv, (name, ib.n_float_textures, ib.n_palettized_textures)
+        assert ic.n_float_textures == n_conv and ic.n_palettized_textures == 0
+        ra, rb, rc = (g.render_round(a.camera, prm, tiles)[0] for g in (ga, gb, gc))
+        record_parity("test_float_textures_with_few_values_take_the_byte_path:" + name, textures=n_conv,
+                      u8_vs_palettized_bit_identical=float((ra == rb).all(axis=2).mean()), u8_vs_float4_bit_identical=float((ra == rc).all(axis=2).mean()))
+        assert np.array_equal(ra, rb) and np.array_equal(ra, rc), name
+        for g in (ga, gb, gc):
+            g.close()
+    # texel-level: bytes, palettized floats and float4 storage return the same bits from GetPixelInterpolated / GetSlope*
+    lib = capi.load_product()
+    rng = np.random.default_rng(77)
+    sb = SceneBuilder()
+    many = rng.random((40, 50, 3)).astype(np.float32)                       # 6000 distinct values: stays float
+    few = rng.choice(rng.random(200).astype(np.float32), size=(33, 47, 3))  # 200 distinct values: byte path
+    m = sb.new_material("m", capi.BXDF_DIFFUSE)
+    m["tex_diffuse"] = sb.add_image_texture("many", many)
+    m2 = sb.new_material("m2", capi.BXDF_DIFFUSE)
+    m2["tex_diffuse"] = sb.add_image_texture("few", few)
+    sb.register_material(m); sb.register_material(m2)
+    from rgk_amd.scene import glm_scale
+    sb.add_primitive("plane", glm_scale((1, 1, 1)), "m"); sb.add_primitive("plane", glm_scale((2, 1, 2)), "m2")
+    g1 = rd.Scene(sb.to_desc())
+    sb.build_flags = capi.BUILD_KEEP_FLOAT_TEXTURES
+    g2 = rd.Scene(sb.to_desc())
+    i1, i2 = g1.info(), g2.info()
+    assert (i1.n_float_textures, i1.n_palettized_textures) == (2, 1) and (i2.n_float_textures, i2.n_palettized_textures) == (2, 0)
+    uv = rng.uniform(-2, 3, (50000, 2)).astype(np.float32)
+    for tex in (0, 1):
+        out = []
+        for g in (g1, g2):
+            rgb = np.zeros((len(uv), 3), np.float32); sr = np.zeros(len(uv), np.float32); sbm = np.zeros(len(uv), np.float32)
+            assert lib.rgk_texture_sample(g.h, len(uv), np.full(len(uv), tex, np.int32).ctypes.data, uv.ctypes.data, rgb.ctypes.data, sr.ctypes.data, sbm.ctypes.data) == 0
+            out.append((rgb, sr, sbm))
+        for x, y in zip(out[0], out[1]):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), tex
