@@ -222,102 +222,130 @@ def main():
         tot = local
     paths, path_rays, shadow_rays = tot
 
-    # ---- rooflines.  LIVE in this run: HIP-event time per kernel class inside the timed steps, the traversal counters of one
-    # extra untimed counting round (deterministic per seed), and each class's compulsory STREAMING bytes (queue records it must
-    # read and write once: exact, from the queue counters).  FROM THE COMMITTED PROFILE of this same command
-    # (profiles/<tag>_roofline.json, tools/profile_round.sh + tools/summarize_prof.py): the VALU instruction mix, lane
-    # utilisation and the physical HBM bytes (rocprofv3 --pmc; bench.py cannot run the profiler on itself) -- attached only
-    # when workload, batch and N match the profiled run, and always with their source named.
-    ms = {"k_trace_closest": sum(c.ms_trace for c in cnts), "k_trace_shadow": sum(c.ms_shadow for c in cnts),
-          "k_shade": sum(c.ms_shade for c in cnts), "raygen_resolve": sum(c.ms_other for c in cnts)}
-    nl = {"k_trace_closest": sum(c.n_trace_launches for c in cnts), "k_trace_shadow": sum(c.n_shadow_launches for c in cnts),
-          "k_shade": sum(c.n_shade_launches for c in cnts)}
+    # ---- a frame's FIRST round (BASELINE configs[2] is `rounds: 1`): the timed steps above are later rounds of one frame -- camera-ray
+    # entry lists capped behind round 1's first hits, per-frame lists cached.  Resetting the per-frame state (what a new camera
+    # or tile list does) makes the next round pay for all of it: uncapped lists, the distance ranges, the list builds.
+    first_round_ms = None
+    if world == 1 and not args.emulate_shard:
+        fr = []
+        for _ in range(3):
+            scene.set_tuning(entry_points=1)   # (same value: the call drops the per-frame lists)
+            barrier()
+            t1 = time.perf_counter()
+            drv.render_round()
+            barrier()
+            fr.append((time.perf_counter() - t1) * 1e3)
+        first_round_ms = round(sorted(fr)[1], 3)
+
+    # ---- rooflines.  LIVE in this run: HIP-event time, launches and units (rays / vertices) PER KERNEL inside the timed steps
+    # (rgk_counters.kernel[], events on the stream the kernels run on), and each kernel's node visits / triangle tests from one
+    # extra untimed counting round (deterministic per seed) -> SURVEY 8(d)'s algorithmic bytes per launch.  FROM THE COMMITTED
+    # PROFILE of this same command (profiles/<tag>_<workload>_roofline.json: tools/profile_round.sh + tools/summarize_prof.py): the
+    # VALU instruction mix, lane utilisation and the physical HBM bytes per launch (rocprofv3 --pmc in separate passes; bench.py
+    # cannot run the profiler on itself) -- attached only when workload and N match the profiled run, always with their source.
+    KID = capi.KERNEL_IDS
     P_l, R_l, S_l = (sum(c.paths for c in cnts), sum(c.path_rays for c in cnts), sum(c.shadow_rays for c in cnts))  # this rank
     drv_c = rd.RenderDriver(scene, Cfg, wl.camera, rank=rank, world_size=world, device=device, flags=capi.FLAG_COUNT_TRAVERSAL,
                             host_reduce=(args.backend != "nccl"))
     cc = drv_c.render_round(reduce=False)
     nodes_per_ray = cc.node_visits / max(1, cc.path_rays)
     tris_per_ray = cc.tri_tests / max(1, cc.path_rays)
-    # SURVEY 8(d) algorithmic bytes per closest-hit ray: 32 (ray) + 4 (ignore id) + 16 (hit) + N_node*s_node + N_tri*s_tri.
-    # Node and triangle bytes are served by L1 / L2 / Infinity Cache, so this figure is NOT a fraction of HBM bandwidth
-    # (round 1 reported it as one: 1.78); it is kept as the algorithmic rate only.
     bytes_per_ray = 32 + 4 + 16 + nodes_per_ray * info.node_bytes + tris_per_ray * info.tri_bytes
-    stream = {  # bytes every launch of the class must move through HBM once (records in, records out), summed over the timed steps
-        "k_trace_closest": 48.0 * R_l - 32.0 * P_l,                      # ray 32 in (bounce 0 makes its camera rays itself), hit 16 out
-        "k_trace_shadow": 48.0 * S_l,                                    # shadow ray 48 in (+ the slot sums of visible ones)
-        # hit 16 + seed 4 per vertex; ray 32 + light 16 + path state 16 in per vertex past the first; path state 16 + light 16 (first
-        # vertex) + next ray 32 out per continuing path; slot sum 16 out per path; shadow ray 48 out
-        "k_shade": 20.0 * R_l + 64.0 * (R_l - P_l) + (48.0 + 16.0) * (R_l - P_l) + 16.0 * P_l + 48.0 * S_l,
-        "raygen_resolve": 16.0 * P_l,                                    # resolve: slot sum 16 in (there is no ray-generation kernel)
-    }
+    # SURVEY 8(d) per shaded vertex: 56 path state + 96 vertex attributes + 32 material (+ 4*12*n_maps texels, n_maps = 2, + 3*12 bump
+    # + 4*20 LTC entries for a textured, bump-mapped LTC material: the Sponza kind) -- 184 B for Cornell's solid diffuse, 396 B otherwise
+    shade_bytes = 184.0 if args.workload.startswith("cornell") else 396.0
     prof, prof_name = None, None
     try:
-        if args.workload == "sponza-1080p" and args.scale == 1.0 and args.spp is None and world == 1:
-            prof_name = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_roofline.json"))[-1]
-            prof = json.load(open(os.path.join(ROOT, "profiles", prof_name)))["kernels"]
+        if args.scale == 1.0 and args.spp is None and world == 1 and not args.emulate_shard:
+            cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith(f"_{args.workload}_roofline.json"))
+            if cands:
+                prof_name = cands[-1]
+                prof = json.load(open(os.path.join(ROOT, "profiles", prof_name)))["kernels"]
     except Exception:
         prof = None
 
-    def prof_rec(kernel):
-        """Launch-weighted sum of the profiled instantiations of a kernel class (the non-counting ones): k_trace_closest =
-        k_trace_camera (bounce 0) + k_trace_closest (later bounces), k_shade = its first-bounce and later-bounce variants."""
-        if not prof:
+    def prof_rec(kid):
+        """The profiled record of one kernel: the non-counting instantiation whose name starts with the kernel's prefix."""
+        pre = capi.KERNEL_NAMES.get(kid)
+        if not prof or not pre:
             return None
-        names = {"k_trace_closest": ("k_trace_camera<false", "k_trace_closest<false"), "k_trace_shadow": ("k_trace_shadow<false", "k_trace_shadow_first<false"),
-                 "k_shade": ("k_shade<false, true>", "k_shade<false, false>"), "raygen_resolve": ("k_resolve",)}[kernel]
-        recs = [r for k, r in prof.items() if k.startswith(names)]
+        recs = [r for k, r in prof.items() if k.startswith(pre) and "<true, 256" not in k and "<true, 32" not in k]
         if not recs:
             return None
         n = sum(r["launches_profiled"] for r in recs)
         w = lambda key: sum((r.get(key) or 0.0) * r["launches_profiled"] for r in recs) / n
         return {"avg_ms": w("avg_ms"), "valu_slow_pipe_cycles": w("valu_slow_pipe_cycles"), "valu_issue_cycles": w("valu_issue_cycles"),
-                "valu_slow_pipe_frac": w("valu_slow_pipe_frac"), "lane_util": w("lane_util"), "hbm_bytes_per_launch": w("hbm_bytes_per_launch") or None}
+                "lane_util": w("lane_util"), "hbm_bytes_per_launch": w("hbm_bytes_per_launch") or None, "launches_profiled": n}
 
-    kernels = []
-    for k in ("k_trace_closest", "k_shade", "k_trace_shadow", "raygen_resolve"):
-        t = ms[k] * 1e-3
-        rec = {"kernel": k, "ms_per_step": round(ms[k] / args.steps, 3), "launches": nl.get(k),
-               "avg_launch_ms": round(ms[k] / max(1, nl.get(k, 0)), 4) if nl.get(k) else None,
-               "stream_GBps": round(stream[k] / t / 1e9, 1) if t > 0 else None,
-               "stream_frac_of_hbm": round(stream[k] / t / 8.0e12, 4) if t > 0 else None}
-        pr = prof_rec(k)
-        if pr and rec["avg_launch_ms"]:
-            live_s = rec["avg_launch_ms"] * 1e-3
-            rec.update({
-                "source": f"profiles/{prof_name}", "profile_avg_launch_ms": round(pr["avg_ms"], 4),
-                # VALU: the non-fp32 ("slow") pipe's busy cycles from the profiled instruction mix (tools/summarize_prof.py), against
-                # 1024 SIMDs x 2.4 GHz x the LIVE launch time; beside it the same fraction at the clock the profiled pass held
-                "valu_slow_pipe_frac": round(pr["valu_slow_pipe_cycles"] / (1024 * 2.4e9 * live_s), 4),
-                "valu_slow_pipe_frac_at_measured_clock": round(pr["valu_slow_pipe_frac"], 4),
-                "valu_issue_frac": round(pr["valu_issue_cycles"] / (1024 * 2.4e9 * live_s), 4), "lane_util": round(pr["lane_util"], 4),
-                "hbm_bytes_per_launch": pr.get("hbm_bytes_per_launch"),
-                "hbm_frac": round(pr["hbm_bytes_per_launch"] / live_s / 8.0e12, 4) if pr.get("hbm_bytes_per_launch") else None})
+    kernels, step_hbm_bytes, step_hbm_covered_ms = [], 0.0, 0.0
+    for i, kid in enumerate(KID):
+        ms_k = sum(c.kernel[i].ms for c in cnts)
+        n_k = sum(c.kernel[i].launches for c in cnts)
+        u_k = sum(c.kernel[i].units for c in cnts)
+        if n_k == 0:
+            continue
+        avg_s = ms_k / n_k * 1e-3
+        rec = {"kernel": kid, "ms_per_step": round(ms_k / args.steps, 3), "launches_per_step": round(n_k / args.steps, 2),
+               "avg_launch_ms": round(ms_k / n_k, 4), "units_per_step": int(u_k / args.steps)}
+        ck = cc.kernel[i]
+        alg = None   # SURVEY 8(d) algorithmic bytes per unit
+        if kid in ("trace_camera", "trace_closest", "light_trace") and ck.units:
+            rec["nodes_per_ray"], rec["tris_per_ray"] = round(ck.node_visits / ck.units, 2), round(ck.tri_tests / ck.units, 2)
+            alg = 32 + 4 + 16 + ck.node_visits / ck.units * info.node_bytes + ck.tri_tests / ck.units * info.tri_bytes
+        elif kid in ("shadow_first", "shadow", "light_splat") and ck.units:
+            rec["nodes_per_ray"], rec["tris_per_ray"] = round(ck.node_visits / ck.units, 2), round(ck.tri_tests / ck.units, 2)
+            alg = 32 + 4 + ck.node_visits / ck.units * info.node_bytes + ck.tri_tests / ck.units * info.tri_bytes
+        elif kid in ("shade_first", "shade"):
+            alg = shade_bytes
+        elif kid == "resolve":
+            alg = 16.0
+        if alg is not None and u_k:
+            per_launch = alg * u_k / n_k
+            rec.update({"algorithmic_bytes_per_unit": round(alg, 1), "algorithmic_bytes_per_launch": round(per_launch),
+                        "algorithmic_GBps": round(per_launch / avg_s / 1e9, 1), "algorithmic_frac_of_hbm_peak": round(per_launch / avg_s / 8.0e12, 4)})
+        pr = prof_rec(kid)
+        if pr:
+            rec.update({"source": f"profiles/{prof_name}", "profile_avg_launch_ms": round(pr["avg_ms"], 4),
+                        # VALU: the non-fp32 ("slow") pipe's busy cycles from the profiled instruction mix (tools/summarize_prof.py) against
+                        # 1024 SIMDs x 2.4 GHz x the LIVE launch time
+                        "valu_slow_pipe_frac": round(pr["valu_slow_pipe_cycles"] / (1024 * 2.4e9 * avg_s), 4),
+                        "valu_issue_frac": round(pr["valu_issue_cycles"] / (1024 * 2.4e9 * avg_s), 4), "lane_util": round(pr["lane_util"], 4)})
+            if pr.get("hbm_bytes_per_launch"):
+                # physical bytes: 128 B per TCC_EA0_RDREQ (= FETCH_SIZE x 2: every read request of these kernels, gathers included, is a
+                # 128-byte line fill -- profiles/r03_fetch_calibration.txt) + WRITE_SIZE
+                rec.update({"hbm_bytes_per_launch": pr["hbm_bytes_per_launch"], "hbm_frac": round(pr["hbm_bytes_per_launch"] / avg_s / 8.0e12, 4)})
+                step_hbm_bytes += pr["hbm_bytes_per_launch"] * n_k / args.steps
+                step_hbm_covered_ms += ms_k / args.steps
         kernels.append(rec)
-    dom = max(kernels[:3], key=lambda r: r["ms_per_step"])
-    if dom["kernel"] == "k_shade":      # gathers + queue records: bounded by the memory system
-        bound, unit, peak = "hbm", "GB/s", 8000.0
-        achieved = (dom["hbm_bytes_per_launch"] / (dom["avg_launch_ms"] * 1e-3) / 1e9) if dom.get("hbm_bytes_per_launch") else dom["stream_GBps"]
-        traffic = dom.get("hbm_bytes_per_launch")
-    else:                                # traversal: bounded by VALU issue (DESIGN.md 6), not by HBM
+    ms_step = elapsed / args.steps * 1e3
+    dom = max((r for r in kernels if r["kernel"] not in ("other",)), key=lambda r: r["ms_per_step"])
+    traversal = dom["kernel"] in ("trace_camera", "trace_closest", "shadow_first", "shadow", "shadow_jobs", "light_trace", "light_splat")
+    if traversal:   # bounded by the VALU's non-fp32 pipe (DESIGN.md 6), not by HBM: its bytes are cache-served
         bound, unit, peak = "valu", "G SIMD-cycles/s of the non-fp32 VALU pipe", 1024 * 2.4
-        pr = prof_rec(dom["kernel"])
-        achieved = (pr["valu_slow_pipe_cycles"] / (dom["avg_launch_ms"] * 1e-3) / 1e9) if pr else None
-        traffic = dom.get("hbm_bytes_per_launch")
-    roofline = {"bound": bound, "kernel": dom["kernel"], "achieved": round(achieved, 1) if achieved else None, "peak": peak, "unit": unit,
-                "frac": round(achieved / peak, 4) if achieved else None, "traffic": traffic,
-                "traffic_source": f"profiles/{prof_name} (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE of this command)" if traffic else None,
-                "lane_util": dom.get("lane_util"), "hbm_frac": dom.get("hbm_frac"),
-                "algorithmic": {"note": "SURVEY 8(d) bytes per ray over launch time; cache-served, not an HBM fraction",
-                                "GBps": round(bytes_per_ray * R_l / (ms["k_trace_closest"] * 1e-3) / 1e9, 1) if ms["k_trace_closest"] > 0 else None,
-                                "bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(nodes_per_ray, 2), "tris_per_ray": round(tris_per_ray, 2),
-                                "node_bytes": info.node_bytes, "tri_bytes": info.tri_bytes,
-                                "rays_per_s_closest": round(R_l / (ms["k_trace_closest"] * 1e-3) / 1e9, 3) if ms["k_trace_closest"] > 0 else None,
-                                # SURVEY 8(d) per shaded vertex: 56 path state + 96 vertex attributes + 32 material + 4*12*n_maps texels
-                                # (n_maps = 2) + 3*12 bump + 4*20 LTC entries = 396 B for a textured, bump-mapped LTC material (the Sponza
-                                # kind), over the shading launches' time; vertices = closest-hit rays.  Also cache-served: coherent first
-                                # vertices share their records (physical: kernels[k_shade].hbm_bytes_per_launch)
-                                "shade_bytes_per_vertex": 396,
-                                "shade_GBps": round(396.0 * R_l / (ms["k_shade"] * 1e-3) / 1e9, 1) if ms["k_shade"] > 0 else None},
+        frac = dom.get("valu_slow_pipe_frac")
+        achieved = frac * peak if frac is not None else None
+    else:           # shading / resolve: gathers + queue records, bounded by the memory system
+        bound, unit, peak = "hbm", "GB/s", 8000.0
+        achieved = (dom["hbm_bytes_per_launch"] / (dom["avg_launch_ms"] * 1e-3) / 1e9) if dom.get("hbm_bytes_per_launch") else dom.get("algorithmic_GBps")
+        frac = achieved / peak if achieved else None
+    roofline = {"bound": bound, "kernel": capi.KERNEL_NAMES.get(dom["kernel"], dom["kernel"]), "kernel_id": dom["kernel"],
+                "avg_launch_ms": dom["avg_launch_ms"], "achieved": round(achieved, 1) if achieved else None, "peak": peak, "unit": unit,
+                "frac": round(frac, 4) if frac is not None else None,
+                "traffic": dom.get("hbm_bytes_per_launch"),
+                "traffic_source": f"profiles/{prof_name}: rocprofv3 --pmc, 128 B x TCC_EA0_RDREQ (= FETCH_SIZE x 2, calibrated for gathers too: profiles/r03_fetch_calibration.txt) + WRITE_SIZE" if dom.get("hbm_bytes_per_launch") else None,
+                "hbm_frac": dom.get("hbm_frac"), "lane_util": dom.get("lane_util"),
+                # SURVEY 8(d)'s figure for the same kernel: algorithmic bytes per launch over the live launch time.  Node and triangle
+                # bytes are served by L1 / L2 / Infinity Cache, so for traversal this exceeds what HBM could deliver: it is the
+                # algorithmic rate, NOT an HBM fraction (the physical one is hbm_frac)
+                "algorithmic": {k: dom.get(k) for k in ("algorithmic_bytes_per_unit", "algorithmic_bytes_per_launch", "algorithmic_GBps", "algorithmic_frac_of_hbm_peak", "nodes_per_ray", "tris_per_ray")},
+                # the north-star target (>= 40 % of the HBM roofline on Sponza 1080p x 256) is judged on THIS: physical bytes of all
+                # kernels of a step over the step's wall time
+                "step_hbm_frac": round(step_hbm_bytes / (ms_step * 1e-3) / 8.0e12, 4) if step_hbm_bytes else None,
+                "step_hbm_GB": round(step_hbm_bytes / 1e9, 2) if step_hbm_bytes else None,
+                "step_algorithmic_GB": round(sum(r.get("algorithmic_bytes_per_launch", 0) * r["launches_per_step"] for r in kernels) / 1e9, 1),
+                "first_round_ms": first_round_ms,
+                "whole_round": {"nodes_per_path_ray": round(nodes_per_ray, 2), "tris_per_path_ray": round(tris_per_ray, 2), "bytes_per_path_ray": round(bytes_per_ray, 1),
+                                "node_bytes": info.node_bytes, "tri_bytes": info.tri_bytes},
                 "kernels": kernels}
 
     metric_name = {"sponza-1080p": "Sponza 1920x1080x256spp", "cornell-1024": "Cornell box 1024x1024x256spp", "cornell-256": "Cornell box 256x256x16spp",
@@ -360,8 +388,16 @@ def main():
         n_tiles = min(n_tiles, len(otiles))
         c, dt = run(n_tiles, capi.SAMPLER_HALTON)
         cs, dts = run(max(threads, n_tiles // 4), capi.SAMPLER_STRATIFIED)
+        cpu_model, sockets = "unknown", None
+        try:
+            ci = open("/proc/cpuinfo").read()
+            cpu_model = next(ln.split(":", 1)[1].strip() for ln in ci.splitlines() if ln.startswith("model name"))
+            sockets = len({ln.split(":", 1)[1].strip() for ln in ci.splitlines() if ln.startswith("physical id")}) or None
+        except (OSError, StopIteration):
+            pass
         out["cpu_baseline"] = {
             "value": round(c.paths / dt / 1e6, 3), "unit": "Mpaths/s", "cores": threads, "kind": "port",
+            "cpu_model": cpu_model, "sockets": sockets, "logical_cpus_visible": os.cpu_count(),
             "sample": f"first {n_tiles} of {len(otiles)} centre-out 32x32 tiles at {wl.multisample} spp, {dt:.1f} s, shared Halton sampler",
             "mrays_per_s_path": round(c.path_rays / dt / 1e6, 3),
             "faithful_sampler_value": round(cs.paths / dts / 1e6, 3),

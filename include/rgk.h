@@ -191,6 +191,33 @@ typedef struct rgk_tile {
     uint32_t seed;
 } rgk_tile;
 
+/* The kernels of a round, for the per-kernel records in rgk_counters: RGK_FLAG_TIME_KERNELS / RGK_FLAG_COUNT_TRAVERSAL. */
+typedef enum rgk_kernel_id {
+    RGK_K_TRACE_CAMERA = 0, /* k_trace_camera: bounce 0, camera rays made where they are traced          */
+    RGK_K_TRACE_CLOSEST,    /* k_trace_closest: camera-path bounces >= 1                                 */
+    RGK_K_SHADE_FIRST,      /* k_shade<., FIRST = true>: the first vertex of every path                  */
+    RGK_K_SHADE,            /* k_shade<., FIRST = false>: later vertices                                 */
+    RGK_K_SHADOW_FIRST,     /* k_trace_shadow_first: first-vertex NEE rays from light-side entry nodes   */
+    RGK_K_SHADOW,           /* k_trace_shadow: NEE rays                                                  */
+    RGK_K_SHADOW_JOBS,      /* k_trace_shadow_jobs: vertices with connections (reverse > 0)              */
+    RGK_K_CONNECT,          /* k_connect (reverse > 0)                                                   */
+    RGK_K_LIGHT_TRACE,      /* k_trace_closest of the light sub-path (reverse > 0)                       */
+    RGK_K_LIGHT_SHADE,      /* k_raygen_light + k_list_hits + k_shade_light                              */
+    RGK_K_LIGHT_SPLAT,      /* k_trace_shadow in splat mode: light-tracing side effects                  */
+    RGK_K_RESOLVE,          /* k_resolve[_tiled]                                                         */
+    RGK_K_OTHER,            /* per-round / per-frame lists, counters, progress marks                     */
+    RGK_K_COUNT
+} rgk_kernel_id;
+
+typedef struct rgk_kernel_stat {
+    double ms;            /* RGK_FLAG_TIME_KERNELS: summed HIP-event time on the scene's stream           */
+    uint32_t launches;
+    uint32_t reserved;
+    uint64_t units;       /* rays (trace kernels) / vertices (shade, connect, jobs) / paths (resolve)     */
+    uint64_t node_visits; /* RGK_FLAG_COUNT_TRAVERSAL, trace kernels                                      */
+    uint64_t tri_tests;
+} rgk_kernel_stat;
+
 typedef struct rgk_counters {
     uint64_t paths;        /* pixels * multisample processed                      */
     uint64_t path_rays;    /* reference semantics: raycount++ path_tracer.cpp:126 */
@@ -207,6 +234,7 @@ typedef struct rgk_counters {
     uint32_t n_shadow_launches;
     uint32_t n_shade_launches;
     uint32_t reserved;
+    rgk_kernel_stat kernel[RGK_K_COUNT]; /* the same, per kernel (the four class sums above are sums of these) */
 } rgk_counters;
 
 typedef struct rgk_scene_info {

@@ -81,6 +81,18 @@ class Tile(C.Structure):
                 ("seed", C.c_uint32)]
 
 
+KERNEL_IDS = ["trace_camera", "trace_closest", "shade_first", "shade", "shadow_first", "shadow", "shadow_jobs", "connect",
+              "light_trace", "light_shade", "light_splat", "resolve", "other"]  # rgk_kernel_id
+KERNEL_NAMES = {"trace_camera": "k_trace_camera", "trace_closest": "k_trace_closest", "shade_first": "k_shade<false, true", "shade": "k_shade<false, false",
+                "shadow_first": "k_trace_shadow_first", "shadow": "k_trace_shadow<", "shadow_jobs": "k_trace_shadow_jobs", "connect": "k_connect",
+                "resolve": "k_resolve"}  # prefixes of the kernel names rocprofv3 reports
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("ms", C.c_double), ("launches", C.c_uint32), ("reserved", C.c_uint32), ("units", C.c_uint64),
+                ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64)]
+
+
 class Counters(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("path_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64),
@@ -88,10 +100,10 @@ class Counters(C.Structure):
                 ("ms_trace", C.c_double), ("ms_shadow", C.c_double), ("ms_shade", C.c_double),
                 ("ms_other", C.c_double), ("n_trace_launches", C.c_uint32),
                 ("n_shadow_launches", C.c_uint32), ("n_shade_launches", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("reserved", C.c_uint32), ("kernel", KernelStat * len(KERNEL_IDS))]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        return {k: getattr(self, k) for k, _ in self._fields_ if k not in ("reserved", "kernel")}
 
 
 class SceneInfo(C.Structure):

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <iterator>
 #include <atomic>
 #include <cmath>
@@ -1319,17 +1320,29 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
         e = s->events[ev_used++];
         return 0;
     };
-#define TIMED(cls_, call)                                                \
+    // counting mode: the traversal counters (stats[0..3]: closest nodes / triangles, shadow nodes / triangles) are read back after
+    // every traversal launch, so that each kernel gets its own share (stream-ordered copies; nobody times a counting round)
+    std::vector<std::pair<int, std::array<unsigned long long, 4>>> snaps;
+    if (count_stats) snaps.reserve(4096);
+#define TIMED(kid_, call)                                                \
     do {                                                                 \
         if (timing) {                                                    \
-            Ev ev; ev.cls = cls_;                                        \
+            Ev ev; ev.cls = (kid_);                                      \
             if ((rc = ev_get(ev.a)) || (rc = ev_get(ev.b))) return rc;   \
             HIPCHK(hipEventRecord(ev.a, st));                            \
             call;                                                        \
             HIPCHK(hipEventRecord(ev.b, st));                            \
             evs.push_back(ev);                                           \
         } else { call; }                                                 \
+        if (count_stats && is_trace_kernel(kid_)) {                      \
+            snaps.emplace_back((int)(kid_), std::array<unsigned long long, 4>{}); \
+            HIPCHK(hipMemcpyAsync(snaps.back().second.data(), s->stats.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st)); \
+            HIPCHK(hipStreamSynchronize(st));                            \
+        }                                                                \
     } while (0)
+    auto is_trace_kernel = [](int k) { return k == RGK_K_TRACE_CAMERA || k == RGK_K_TRACE_CLOSEST || k == RGK_K_SHADOW_FIRST || k == RGK_K_SHADOW ||
+                                              k == RGK_K_SHADOW_JOBS || k == RGK_K_LIGHT_TRACE || k == RGK_K_LIGHT_SPLAT; };
+    uint64_t units[RGK_K_COUNT] = {};
 
     uint64_t path_rays = 0, shadow_rays = 0;
     // progress: one stage per bounce per pass; a one-thread kernel queued behind each bounce writes the stage number into pinned
@@ -1363,7 +1376,7 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
         if ((rc = s->lentry.alloc(groups * RGK_ENTRY_K)) || (rc = s->trange.alloc(groups * 2)) || (rc = s->lbox.alloc(groups * 2))) return rc;
     }
     if ((rc = s->htab.alloc((size_t)192 * prm->multisample))) return rc;
-    TIMED(3, rgk_launch_build_halton_table(st, s->dev, prm->multisample, s->htab.p));
+    TIMED(RGK_K_OTHER, rgk_launch_build_halton_table(st, s->dev, prm->multisample, s->htab.p));
     pp.htab = s->htab.p; pp.light = s->light.p; pp.generic = s->generic.p;
     // Deep path loops (depth > 12): the length of the next queue is read back every other bounce from the fourth on; it
     // bounds the grids of the following launches (queues only shrink) and ends the loop once no path is left.
@@ -1405,47 +1418,47 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
             if (R > 0) {
                 // light sub-path first (its sampler dimensions are fixed), splats straight into the accumulator
                 rgk_launch_set_bound(n0, n0);
-                TIMED(3, rgk_launch_init_counters(st, cl, 0u)); // (k_raygen_light queues the light rays that can touch the scene's box)
-                TIMED(3, rgk_launch_raygen_light(st, s->dev, cam, pp, s->rayA[0].p, s->rayB[0].p, s->thr.p, cl));
+                TIMED(RGK_K_OTHER, rgk_launch_init_counters(st, cl, 0u)); // (k_raygen_light queues the light rays that can touch the scene's box)
+                TIMED(RGK_K_LIGHT_SHADE, rgk_launch_raygen_light(st, s->dev, cam, pp, s->rayA[0].p, s->rayB[0].p, s->thr.p, cl));
                 for (uint32_t k = 0; k < R; k++) {
                     int q = k & 1;
-                    TIMED(0, rgk_launch_trace_closest(st, s->dev, s->tcfg, count_stats, s->rayA[q].p, s->rayB[q].p, nullptr, s->hit.p,
+                    TIMED(RGK_K_LIGHT_TRACE, rgk_launch_trace_closest(st, s->dev, s->tcfg, count_stats, s->rayA[q].p, s->rayB[q].p, nullptr, s->hit.p,
                                                       cl + RGK_CNT_QUEUE + k, cl + RGK_CNT_FETCH_T + k, s->stats.p));
-                    TIMED(3, rgk_launch_list_hits(st, s->hit.p, cl + RGK_CNT_QUEUE + k, s->hitlist.p, cl + RGK_CNT_HITS + k));
-                    TIMED(2, rgk_launch_shade_light(st, s->dev, cam, pp, k, s->rayA[q].p, s->rayB[q].p, s->hit.p, s->thr.p,
+                    TIMED(RGK_K_LIGHT_SHADE, rgk_launch_list_hits(st, s->hit.p, cl + RGK_CNT_QUEUE + k, s->hitlist.p, cl + RGK_CNT_HITS + k));
+                    TIMED(RGK_K_LIGHT_SHADE, rgk_launch_shade_light(st, s->dev, cam, pp, k, s->rayA[q].p, s->rayB[q].p, s->hit.p, s->thr.p,
                                                     s->rayA[q ^ 1].p, s->rayB[q ^ 1].p, s->shA.p, s->shB.p, s->shC.p, cl));
-                    TIMED(1, rgk_launch_trace_shadow(st, s->dev, s->tcfg, count_stats, s->shA.p, s->shB.p, s->shC.p, nullptr, nullptr,
+                    TIMED(RGK_K_LIGHT_SPLAT, rgk_launch_trace_shadow(st, s->dev, s->tcfg, count_stats, s->shA.p, s->shB.p, s->shC.p, nullptr, nullptr,
                                                      RGK_SHADOW_SPLAT, d_accum_rgb, cl + RGK_CNT_SHADOW + k, cl + RGK_CNT_FETCH_S + k, s->stats.p));
                 }
             }
             {   // the camera path: the same pipeline for uni- and bidirectional rounds (R > 0: vertices with connections take
                 // the record route -- k_shade<BDPT> -> k_connect -> k_trace_shadow_jobs -- beside the plain NEE rays)
-                TIMED(3, rgk_launch_init_counters(st, cn, n0));
+                TIMED(RGK_K_OTHER, rgk_launch_init_counters(st, cn, n0));
                 uint32_t ub = n0; // upper bound on bounce b's queue
                 for (uint32_t b = 0; b < prm->depth && ub > 0; b++) {
                     int q = b & 1;
                     rgk_launch_set_bound(ub, ub);
                     if (b == 0) // no ray queue at bounce 0: the camera ray of slot i is made where it is traced and shaded
-                        TIMED(0, rgk_launch_trace_camera(st, s->dev, cam, pp, s->tcfg, count_stats, s->hit.p, cn + RGK_CNT_QUEUE, cn + RGK_CNT_FETCH_T, s->stats.p));
+                        TIMED(RGK_K_TRACE_CAMERA, rgk_launch_trace_camera(st, s->dev, cam, pp, s->tcfg, count_stats, s->hit.p, cn + RGK_CNT_QUEUE, cn + RGK_CNT_FETCH_T, s->stats.p));
                     else
-                        TIMED(0, rgk_launch_trace_closest(st, s->dev, s->tcfg, count_stats, s->rayA[q].p, s->rayB[q].p, nullptr, s->hit.p,
+                        TIMED(RGK_K_TRACE_CLOSEST, rgk_launch_trace_closest(st, s->dev, s->tcfg, count_stats, s->rayA[q].p, s->rayB[q].p, nullptr, s->hit.p,
                                                           cn + RGK_CNT_QUEUE + b, cn + RGK_CNT_FETCH_T + b, s->stats.p));
                     if (b == 0 && (cap_entries || light_entry)) {
                         // once per frame and pixel range (later rounds and sample ranges reuse it): how far the first hits of each
                         // pixel group lie -> camera-ray entry lists capped behind them, and where the group's shadow rays can go
                         const bool need_cap = cap_entries && (size_t)pp.j0 + pp.npix > s->entry_capped;
                         const bool need_light = light_entry && (size_t)pp.j0 + pp.npix > s->lentry_done;
-                        if (need_cap || need_light) TIMED(3, rgk_launch_group_trange(st, pp, s->hit.p, s->trange.p));
+                        if (need_cap || need_light) TIMED(RGK_K_OTHER, rgk_launch_group_trange(st, pp, s->hit.p, s->trange.p));
                         if (need_cap) {
                             const uint32_t g_first = pp.j0 >> RGK_ENTRY_SHIFT, g_last = (uint32_t)(((size_t)pp.j0 + pp.npix + RGK_ENTRY_PIX - 1) >> RGK_ENTRY_SHIFT);
-                            TIMED(3, rgk_launch_entry_points(st, s->dev, cam, prm->xres, prm->yres, s->pix_xy.p, (uint32_t)P, g_first, g_last - g_first, s->trange.p, s->entry.p, s->entry_cap.p));
+                            TIMED(RGK_K_OTHER, rgk_launch_entry_points(st, s->dev, cam, prm->xres, prm->yres, s->pix_xy.p, (uint32_t)P, g_first, g_last - g_first, s->trange.p, s->entry.p, s->entry_cap.p));
                             s->entry_capped = (size_t)pp.j0 + pp.npix;
                         }
                     }
                     if (b == 0 && light_entry) {
                         pp.lentry = s->lentry.p; pp.lbox = s->lbox.p;
                         if ((size_t)pp.j0 + pp.npix > s->lentry_done) {
-                            TIMED(3, rgk_launch_light_entry_points(st, s->dev, cam, pp, (uint32_t)P, s->trange.p, s->lentry.p, s->lbox.p));
+                            TIMED(RGK_K_OTHER, rgk_launch_light_entry_points(st, s->dev, cam, pp, (uint32_t)P, s->trange.p, s->lentry.p, s->lbox.p));
                             s->lentry_done = (size_t)pp.j0 + pp.npix;
                             if (s->tune.debug_bvh) { // how many pixel groups got light-side entry nodes below the root
                                 const size_t g0 = pp.j0 >> RGK_ENTRY_SHIFT, g1 = ((size_t)pp.j0 + pp.npix + RGK_ENTRY_PIX - 1) >> RGK_ENTRY_SHIFT;
@@ -1458,28 +1471,42 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
                             }
                         }
                     }
-                    TIMED(2, rgk_launch_shade(st, s->dev, cam, pp, b, s->rayA[q].p, s->rayB[q].p, s->hit.p, s->thr.p, s->tot.p,
+                    TIMED(b == 0 ? RGK_K_SHADE_FIRST : RGK_K_SHADE, rgk_launch_shade(st, s->dev, cam, pp, b, s->rayA[q].p, s->rayB[q].p, s->hit.p, s->thr.p, s->tot.p,
                                               s->rayA[q ^ 1].p, s->rayB[q ^ 1].p, s->shA.p, s->shB.p, s->shC.p, cn, R > 0));
-                    if (R > 0) TIMED(2, rgk_launch_connect(st, s->dev, pp, b, s->jobs.p, s->rads.p, cn));
+                    if (R > 0) TIMED(RGK_K_CONNECT, rgk_launch_connect(st, s->dev, pp, b, s->jobs.p, s->rads.p, cn));
                     if (b == 0 && light_entry)
-                        TIMED(1, rgk_launch_trace_shadow_first(st, s->dev, pp, s->tcfg, count_stats, s->shA.p, s->shB.p, s->shC.p, s->tot.p,
+                        TIMED(RGK_K_SHADOW_FIRST, rgk_launch_trace_shadow_first(st, s->dev, pp, s->tcfg, count_stats, s->shA.p, s->shB.p, s->shC.p, s->tot.p,
                                                                cn + RGK_CNT_SHADOW + b, cn + RGK_CNT_FETCH_S + b, s->stats.p));
                     else
-                        TIMED(1, rgk_launch_trace_shadow(st, s->dev, s->tcfg, count_stats, s->shA.p, s->shB.p, s->shC.p, s->tot.p, nullptr,
+                        TIMED(RGK_K_SHADOW, rgk_launch_trace_shadow(st, s->dev, s->tcfg, count_stats, s->shA.p, s->shB.p, s->shC.p, s->tot.p, nullptr,
                                                          RGK_SHADOW_ADD, nullptr, cn + RGK_CNT_SHADOW + b, cn + RGK_CNT_FETCH_S + b, s->stats.p));
                     if (R > 0) // (after the plain rays: both add into the slot sums, a slot has a vertex in ONE of the two queues)
-                        TIMED(1, rgk_launch_trace_shadow_jobs(st, s->dev, pp, s->tcfg, count_stats, s->jobs.p, s->rads.p, s->tot.p,
+                        TIMED(RGK_K_SHADOW_JOBS, rgk_launch_trace_shadow_jobs(st, s->dev, pp, s->tcfg, count_stats, s->jobs.p, s->rads.p, s->tot.p,
                                                               cn + RGK_CNT_CONN + b, cn + RGK_CNT_FETCH_J + b, s->stats.p));
                     if ((rc = stage_mark(stage_target + b + 1))) return rc;
                     if (track && b >= 3 && (b & 1) && b + 1 < prm->depth && (rc = queue_len(cn + RGK_CNT_QUEUE + b + 1, ub))) return rc;
                 }
             }
-            TIMED(3, rgk_launch_resolve(st, pp, s->tot.p, s->pixsum.p, d_accum_rgb, d_accum_count));
+            TIMED(RGK_K_RESOLVE, rgk_launch_resolve(st, pp, s->tot.p, s->pixsum.p, d_accum_rgb, d_accum_count));
             stage_target += std::max(1u, prm->depth);
             if ((rc = stage_mark(stage_target))) return rc;
             HIPCHK(hipMemcpyAsync(s->h_counters, s->counters.p, 2 * RGK_CNT_TOTAL * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
             for (uint32_t b = 0; b < prm->depth; b++) { path_rays += s->h_counters[RGK_CNT_QUEUE + b]; shadow_rays += s->h_counters[RGK_CNT_SHADOW + b] + s->h_counters[RGK_CNT_SRAYS + b]; }
+            {   // what each kernel processed in this pass: rays / vertices, from the queue counters
+                const uint32_t* hc = s->h_counters;
+                units[RGK_K_TRACE_CAMERA] += hc[RGK_CNT_QUEUE]; units[RGK_K_SHADE_FIRST] += hc[RGK_CNT_QUEUE];
+                for (uint32_t b = 1; b < prm->depth; b++) { units[RGK_K_TRACE_CLOSEST] += hc[RGK_CNT_QUEUE + b]; units[RGK_K_SHADE] += hc[RGK_CNT_QUEUE + b]; }
+                for (uint32_t b = 0; b < prm->depth; b++) {
+                    units[(b == 0 && light_entry) ? RGK_K_SHADOW_FIRST : RGK_K_SHADOW] += hc[RGK_CNT_SHADOW + b];
+                    units[RGK_K_SHADOW_JOBS] += hc[RGK_CNT_CONN + b]; units[RGK_K_CONNECT] += hc[RGK_CNT_CONN + b];
+                }
+                for (uint32_t k = 0; k < R; k++) {
+                    units[RGK_K_LIGHT_TRACE] += hc[RGK_CNT_TOTAL + RGK_CNT_QUEUE + k]; units[RGK_K_LIGHT_SHADE] += hc[RGK_CNT_TOTAL + RGK_CNT_HITS + k];
+                    units[RGK_K_LIGHT_SPLAT] += hc[RGK_CNT_TOTAL + RGK_CNT_SHADOW + k];
+                }
+                units[RGK_K_RESOLVE] += n0;
+            }
             // (light rays: the reference traces and counts one per path, path_tracer.cpp:126,349 -- the ones culled before the queue included)
             for (uint32_t k = 0; k < R; k++) { path_rays += k == 0 ? n0 : s->h_counters[RGK_CNT_TOTAL + RGK_CNT_QUEUE + k]; shadow_rays += s->h_counters[RGK_CNT_TOTAL + RGK_CNT_SHADOW + k]; }
         }
@@ -1498,10 +1525,24 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
         for (auto& e : evs) {
             float ms = 0.f;
             HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
-            if (e.cls == 0) { counters->ms_trace += ms; counters->n_trace_launches++; }
-            else if (e.cls == 1) { counters->ms_shadow += ms; counters->n_shadow_launches++; }
-            else if (e.cls == 2) { counters->ms_shade += ms; counters->n_shade_launches++; }
+            rgk_kernel_stat& ks = counters->kernel[e.cls];
+            ks.ms += ms; ks.launches++;
+            const int k = e.cls;
+            if (k == RGK_K_TRACE_CAMERA || k == RGK_K_TRACE_CLOSEST || k == RGK_K_LIGHT_TRACE) { counters->ms_trace += ms; counters->n_trace_launches++; }
+            else if (k == RGK_K_SHADOW_FIRST || k == RGK_K_SHADOW || k == RGK_K_SHADOW_JOBS || k == RGK_K_LIGHT_SPLAT) { counters->ms_shadow += ms; counters->n_shadow_launches++; }
+            else if (k == RGK_K_SHADE_FIRST || k == RGK_K_SHADE || k == RGK_K_CONNECT || k == RGK_K_LIGHT_SHADE) { counters->ms_shade += ms; counters->n_shade_launches++; }
             else counters->ms_other += ms;
+        }
+        for (int k = 0; k < RGK_K_COUNT; k++) counters->kernel[k].units = units[k];
+        {   // per-kernel traversal counters: differences between consecutive read-backs
+            std::array<unsigned long long, 4> prev{};
+            for (auto& sn : snaps) {
+                rgk_kernel_stat& ks = counters->kernel[sn.first];
+                const bool shadow = !(sn.first == RGK_K_TRACE_CAMERA || sn.first == RGK_K_TRACE_CLOSEST || sn.first == RGK_K_LIGHT_TRACE);
+                ks.node_visits += sn.second[shadow ? 2 : 0] - prev[shadow ? 2 : 0];
+                ks.tri_tests += sn.second[shadow ? 3 : 1] - prev[shadow ? 3 : 1];
+                prev = sn.second;
+            }
         }
     }
     return RGK_OK;

@@ -6,7 +6,7 @@ for e in "$@"; do
 import json
 d=json.load(open("gpurun_out/env_$tag.json"))
 r=d["roofline"]
-print("$e", d["value"], "ms/step", d["ms_per_step"], "nodes", r["algorithmic"]["nodes_per_ray"], "tris", r["algorithmic"]["tris_per_ray"], {k["kernel"]: k["ms_per_step"] for k in r["kernels"]})
+print("$e", d["value"], "ms/step", d["ms_per_step"], "nodes", r["whole_round"]["nodes_per_path_ray"], "tris", r["whole_round"]["tris_per_path_ray"], {k["kernel"]: k["ms_per_step"] for k in r["kernels"]})
 PY
   grep "rgk\] bvh4" gpurun_out/env_$tag.err | head -1
 done

@@ -54,6 +54,13 @@ def find(d, suffix):
 def counters(d):
     """{kernel: {counter: (sum, launches)}} of one --pmc pass directory."""
     out = collections.OrderedDict()
+    f = find(d, "_counter_sums.csv")  # per-kernel sums made on the GPU box by tools/profile_round.sh (the per-dispatch table is tens of MB)
+    if f:
+        for r in csv.DictReader(open(f)):
+            c = out.setdefault(short(r["Kernel_Name"]), {})
+            v, n = c.get(r["Counter_Name"], (0.0, 0))
+            c[r["Counter_Name"]] = (v + float(r["Counter_Value"]), n + int(r["Dispatches"]))
+        return out
     f = find(d, "_counter_collection.csv")
     if not f:
         return out
@@ -92,13 +99,22 @@ def main():
                     m.setdefault(c, vn)
     with open(os.path.join(out, f"{tag}_hbm_traffic.csv"), "w", newline="") as g:
         w = csv.writer(g)
-        w.writerow(["kernel", "launches", "FETCH_SIZE_KB_sum", "WRITE_SIZE_KB_sum", "read_MB_per_launch_x2corrected", "write_MB_per_launch", "hbm_MB_per_launch"])
+        # read bytes: every memory-side read request of these kernels is a 128-byte line fill, sparse gathers included
+        # (profiles/r03_fetch_calibration.txt: TCC_EA0_RDREQ_32B = 0, a second touch of a gathered line hits in L2), while FETCH_SIZE
+        # tallies a request at 64 bytes -- so read bytes = 128 x TCC_EA0_RDREQ = 2 x FETCH_SIZE.  Both are listed when both were collected.
+        w.writerow(["kernel", "launches", "FETCH_SIZE_KB_sum", "WRITE_SIZE_KB_sum", "read_MB_per_launch_x2corrected", "write_MB_per_launch", "hbm_MB_per_launch",
+                    "TCC_EA0_RDREQ_per_launch", "TCC_EA0_RDREQ_32B_per_launch", "read_MB_per_launch_128B_x_RDREQ", "L2_hit_rate"])
         for k, m in merged.items():
             if "FETCH_SIZE" not in m or "WRITE_SIZE" not in m:
                 continue
             (fv, fn), (wv, wn) = m["FETCH_SIZE"], m["WRITE_SIZE"]
             rd, wr = 2.0 * fv * 1024 / max(fn, 1) / 1e6, wv * 1024 / max(wn, 1) / 1e6
-            w.writerow([k, max(fn, wn), round(fv, 1), round(wv, 1), round(rd, 2), round(wr, 2), round(rd + wr, 2)])
+            rq = m.get("TCC_EA0_RDREQ_sum"); r32 = m.get("TCC_EA0_RDREQ_32B_sum"); hit = m.get("TCC_HIT_sum"); miss = m.get("TCC_MISS_sum")
+            rqpl = rq[0] / max(rq[1], 1) if rq else None
+            w.writerow([k, max(fn, wn), round(fv, 1), round(wv, 1), round(rd, 2), round(wr, 2), round(rd + wr, 2),
+                        round(rqpl, 1) if rq else "", round(r32[0] / max(r32[1], 1), 1) if r32 else "",
+                        round((128.0 * (rqpl - r32[0] / max(r32[1], 1)) + 32.0 * r32[0] / max(r32[1], 1)) / 1e6, 2) if rq and r32 else "",
+                        round(hit[0] / max(hit[0] + miss[0], 1), 4) if hit and miss else ""])
     roof = {"tag": tag, "command": "python bench.py --steps 1 --warmup 0 --no-cpu-baseline (one rocprofv3 --pmc pass per counter group); "
                                    "durations from the --kernel-trace --stats pass of bench.py --steps 3 --warmup 1",
             "valu_issue_cost_cycles": COST, "n_simd": N_SIMD, "hbm_peak_GBps": HBM_PEAK / 1e9, "kernels": {}}
@@ -125,6 +141,12 @@ def main():
         if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
             b = 2.0 * per("FETCH_SIZE") * 1024 + per("WRITE_SIZE") * 1024
             rec["hbm_bytes_per_launch"] = b
+            if "TCC_EA0_RDREQ_sum" in m:  # the same read bytes from the raw request counters: 128 B per request (+ 32 B ones, if any)
+                r32 = per("TCC_EA0_RDREQ_32B_sum")
+                rec["read_bytes_per_launch_from_rdreq"] = 128.0 * (per("TCC_EA0_RDREQ_sum") - r32) + 32.0 * r32
+                rec["rdreq_32B_share"] = round(r32 / max(per("TCC_EA0_RDREQ_sum"), 1.0), 6)
+                if "TCC_HIT_sum" in m and "TCC_MISS_sum" in m:
+                    rec["l2_hit_rate"] = round(per("TCC_HIT_sum") / max(per("TCC_HIT_sum") + per("TCC_MISS_sum"), 1.0), 4)
             rec["hbm_GBps"] = round(b / (stats[k]["avg_ms"] * 1e-3) / 1e9, 1)
             rec["hbm_frac"] = round(b / (stats[k]["avg_ms"] * 1e-3) / HBM_PEAK, 4)
         roof["kernels"][k] = rec

@@ -6,6 +6,6 @@ for v in "$@"; do
 import json
 d=json.load(open("gpurun_out/var_$v.json"))
 r=d["roofline"]
-print("variant $v", d["value"], "ms/step", d["ms_per_step"], "nodes", r["algorithmic"]["nodes_per_ray"], {k["kernel"]: k["ms_per_step"] for k in r["kernels"]})
+print("variant $v", d["value"], "ms/step", d["ms_per_step"], "nodes", r["whole_round"]["nodes_per_path_ray"], {k["kernel"]: k["ms_per_step"] for k in r["kernels"]})
 PY
 done
