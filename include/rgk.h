@@ -139,12 +139,14 @@ typedef struct rgk_scene_desc {
     uint32_t build_flags;
 } rgk_scene_desc;
 
-#define RGK_BUILD_HOST_SAH 0u /* binned-SAH on the host, collapsed to the 4-wide quantised BVH (default: best traversal)        */
+#define RGK_BUILD_AUTO 0u     /* default: the host builder below half a million triangle references, the device builder from there on */
+#define RGK_BUILD_HOST_SAH 4u /* binned SAH + reinsertion on the host, collapsed to the 4-wide quantised BVH: the best traversal, seconds
+                                 to build at a million triangles                                                              */
 #define RGK_BUILD_KEEP_FLOAT_TEXTURES 2u /* store every RGK_TEX_RGB32F texture as float4 texels, even one with <= 256 distinct channel
                                             values (by default such a texture is stored as bytes + the table of its values: the same
                                             texel values, a quarter of the traffic)                                                */
-#define RGK_BUILD_DEVICE 1u   /* LBVH on the GPU (Morton sort, Karras hierarchy, refit, collapse + quantisation: all on the device):
-                                 milliseconds instead of a second at 1 M triangles, more node visits per ray                  */
+#define RGK_BUILD_DEVICE 1u   /* LBVH on the GPU (Morton sort, Karras hierarchy, refit with tree rotations, collapse + quantisation: all on
+                                 the device): a tenth of the host's build time, traversal within a few per cent of it        */
 
 /* ---- Camera as RenderRound(const Camera&) receives it (src/render_driver.cpp:146): the public data members
  *      of the reference's Camera, src/camera.hpp:27-41, under their own names (`lookat` is not read on the path).
@@ -275,6 +277,14 @@ int rgk_device_count(void);
 
 /* Scene::Commit() outputs (src/scene.cpp:294-400) + accelerator build + upload. */
 int rgk_scene_create(const rgk_scene_desc *desc, int device, rgk_scene **out);
+/* Moved vertices, same triangles (an animated mesh between two frames; SURVEY 8(f) f2 "refit").  What Scene::Commit derives
+ * from the positions is recomputed -- triangle planes, epsilon = 1e-5 * diagonal, the padded box, the areal-light tables
+ * (src/scene.cpp:294-400) -- and the accelerator is REFIT on the device: its topology stays, every box is recomputed bottom-up
+ * (milliseconds at a million triangles, where a rebuild takes 0.15 - 1.5 s).  Hits are those of a freshly created scene with
+ * the same vertices (they come from the triangle records; boxes only steer the walk); the walk is as good as the old topology
+ * fits the new positions.  vertices: 3 * n_vertices floats; normals / tangents: the same, or NULL = unchanged.  A triangle
+ * that was degenerate at creation is not in the tree and stays out.  Not while a round is in flight on this scene. */
+int rgk_scene_refit(rgk_scene *scene, const float *vertices, const float *normals, const float *tangents);
 void rgk_scene_destroy(rgk_scene *scene);
 int rgk_scene_get_info(const rgk_scene *scene, rgk_scene_info *out);
 

@@ -37,6 +37,9 @@ RGK_HD float rgk_sqrtf_ieee(float x) { return __builtin_sqrtf(x); }
 RGK_HD float rgk_sqrtf_ieee(float x) { return std::sqrt(x); }
 #endif
 RGK_HD double rgk_sqrt(double x) {
+#if defined(RGK_LIBM_BUILTIN_SQRT) /* diagnosis only (tools/gpu_zoo_debug.py): the form that gave run-to-run differences in round 2 */
+    return x > 0.0 ? __builtin_sqrt(x) : 0.0;
+#endif
     if (!(x > 0.0)) return 0.0;
     const double s0 = (double)rgk_sqrtf_ieee((float)x);
     if (!(s0 > 0.0)) return 0.0; /* x below the float range: the path never gets there (x = (1 - |cos|) / 2 of float cosines) */

@@ -17,7 +17,7 @@ TEX_SOLID, TEX_RGB32F, TEX_RGB8 = 0, 1, 2
 SKY_COLOR, SKY_ENVMAP = 0, 1
 SAMPLER_HALTON, SAMPLER_STRATIFIED = 0, 1
 FLAG_COUNT_TRAVERSAL, FLAG_TIME_KERNELS = 1, 2
-BUILD_HOST_SAH, BUILD_DEVICE, BUILD_KEEP_FLOAT_TEXTURES = 0, 1, 2
+BUILD_AUTO, BUILD_DEVICE, BUILD_KEEP_FLOAT_TEXTURES, BUILD_HOST_SAH = 0, 1, 2, 4
 
 BRDF_IDS = {  # Material::LoadFromJson, reference src/bxdf/bxdf.cpp:63-84
     "diffusecosine": BXDF_DIFFUSE, "diffuse": BXDF_DIFFUSE, "mix": BXDF_MIX,
@@ -126,7 +126,7 @@ class Hit(C.Structure):
 
 # every symbol include/rgk.h declares (tests check the .so exports all of them)
 EXPORTS = ["rgk_last_error", "rgk_device_count", "rgk_scene_create", "rgk_scene_destroy",
-           "rgk_scene_get_info", "rgk_scene_get_progress", "rgk_scene_set_tuning", "rgk_generate_task_list", "rgk_camera_init", "rgk_render_round",
+           "rgk_scene_get_info", "rgk_scene_get_progress", "rgk_scene_set_tuning", "rgk_scene_refit", "rgk_generate_task_list", "rgk_camera_init", "rgk_render_round",
            "rgk_render_round_device", "rgk_trace_closest", "rgk_trace_visibility",
            "rgk_bxdf_value", "rgk_bxdf_sample", "rgk_texture_sample",
            "rgk_libm_eval", "rgk_sampler_eval", "rgk_output_normalize", "rgk_output_write_exr", "rgk_float_to_half",
@@ -146,6 +146,7 @@ def _bind(lib):
     lib.rgk_scene_get_info.argtypes = [C.c_void_p, _p(SceneInfo)]
     lib.rgk_scene_get_progress.argtypes = [C.c_void_p, _p(Progress)]
     lib.rgk_scene_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+    lib.rgk_scene_refit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rgk_generate_task_list.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float,
                                            C.c_uint32, C.c_uint32, _p(Tile), _p(C.c_uint32)]
     lib.rgk_camera_init.argtypes = [_p(Camera), f3, f3, f3, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_float, C.c_float]

@@ -5,7 +5,11 @@
 //   2. radix sort of the 64-bit keys (hipcub)
 //   3. LBVH hierarchy, one thread per internal node (Karras 2012: direction, range by exponential + binary search over the
 //      longest common prefix, split)
-//   4. bottom-up refit with one arrival counter per internal node: boxes (epsilon-padded like the host builder's) and subtree sizes
+//   4. bottom-up refit with one arrival counter per internal node: boxes (epsilon-padded like the host builder's) and subtree
+//      sizes -- and, in the same pass, ONE quality step: the thread that completes a node may swap one of its children with a
+//      grandchild on the other side (a tree rotation, Kensler 2008) when that shrinks the surface of the child node in between;
+//      the subtree below is complete and nobody else is in it, so the step needs no locks.  A rotated node's leaves are no longer
+//      one range of the sorted order: it is flagged and never becomes a leaf itself (its intact sub-subtrees do)
 //   5. top-down collapse into the quantised 4-wide nodes the traversal kernels read, one level per launch: a node's children are
 //      its binary children, the one with the largest surface opened again and again until there are four; subtrees of at most
 //      `max_leaf` references become leaves over their (contiguous) range of the sorted order; child boxes are quantised to 8 bits
@@ -116,6 +120,62 @@ __global__ void k_refit(const RgkBuildPrim* __restrict__ prims, const unsigned l
     }
 }
 
+#define RGK_ROTATED 0x80000000u // count[]: the node's leaves are not one range of the sorted order any more
+__device__ __forceinline__ BBox unite(const BBox& a, const BBox& b) {
+    BBox u;
+    for (int x = 0; x < 3; x++) { u.mn[x] = fminf(a.mn[x], b.mn[x]); u.mx[x] = fmaxf(a.mx[x], b.mx[x]); }
+    return u;
+}
+// The same pass with the rotation step (see the header).  count[] carries RGK_ROTATED in its top bit.
+__global__ void k_refit_rotate(const RgkBuildPrim* __restrict__ prims, const unsigned long long* __restrict__ keys, int n, float pad,
+                               int* __restrict__ left, int* __restrict__ right, int* __restrict__ parent,
+                               int* __restrict__ leaf_parent, int* __restrict__ arrived, BBox* __restrict__ nbox, uint32_t* __restrict__ count) {
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        int p = leaf_parent[k];
+        while (p >= 0) {
+            __threadfence();
+            if (atomicAdd(&arrived[p], 1) == 0) break;
+            __threadfence();
+            int lc = left[p], rc = right[p];
+            BBox a = child_box(lc, nbox, prims, keys, pad), b = child_box(rc, nbox, prims, keys, pad);
+            nbox[p] = unite(a, b);
+            const uint32_t cl = lc >= 0 ? (count[lc] & ~RGK_ROTATED) : 1u, cr = rc >= 0 ? (count[rc] & ~RGK_ROTATED) : 1u;
+            count[p] = (cl + cr) | (count[p] & RGK_ROTATED); // (the flag of an earlier pass stays: a rotated node's leaves never become one range again)
+            // rotations: swap `a` (left) with a child of the right node, or `b` (right) with a child of the left node -- the node in
+            // between then bounds {the swapped-in child, its remaining child}; take the swap that shrinks its surface most
+            float best = 0.f;
+            int which = -1;
+            BBox nb{};
+            if (rc >= 0) {
+                const int rl = left[rc], rr = right[rc];
+                const BBox brl = child_box(rl, nbox, prims, keys, pad), brr = child_box(rr, nbox, prims, keys, pad);
+                const float ar = area(b);
+                const BBox u0 = unite(a, brr), u1 = unite(brl, a); // left <-> rl : right node = {left, rr};  left <-> rr : right node = {rl, left}
+                if (ar - area(u0) > best) { best = ar - area(u0); which = 0; nb = u0; }
+                if (ar - area(u1) > best) { best = ar - area(u1); which = 1; nb = u1; }
+            }
+            if (lc >= 0) {
+                const int ll = left[lc], lr = right[lc];
+                const BBox bll = child_box(ll, nbox, prims, keys, pad), blr = child_box(lr, nbox, prims, keys, pad);
+                const float al = area(a);
+                const BBox u2 = unite(b, blr), u3 = unite(bll, b); // right <-> ll : left node = {right, lr};  right <-> lr : left node = {ll, right}
+                if (al - area(u2) > best) { best = al - area(u2); which = 2; nb = u2; }
+                if (al - area(u3) > best) { best = al - area(u3); which = 3; nb = u3; }
+            }
+            if (which >= 0) {
+                auto cnt = [&](int c) { return c >= 0 ? (count[c] & ~RGK_ROTATED) : 1u; };
+                auto adopt = [&](int child, int by) { if (child >= 0) parent[child] = by; else leaf_parent[~child] = by; }; // (the next pass climbs these)
+                if (which == 0) { const int rl = left[rc]; left[p] = rl; left[rc] = lc; count[rc] = (cnt(lc) + cnt(right[rc])) | RGK_ROTATED; nbox[rc] = nb; adopt(rl, p); adopt(lc, rc); }
+                else if (which == 1) { const int rr = right[rc]; left[p] = rr; right[rc] = lc; count[rc] = (cnt(left[rc]) + cnt(lc)) | RGK_ROTATED; nbox[rc] = nb; adopt(rr, p); adopt(lc, rc); }
+                else if (which == 2) { const int ll = left[lc]; right[p] = ll; left[lc] = rc; count[lc] = (cnt(rc) + cnt(right[lc])) | RGK_ROTATED; nbox[lc] = nb; adopt(ll, p); adopt(rc, lc); }
+                else { const int lr = right[lc]; right[p] = lr; right[lc] = rc; count[lc] = (cnt(left[lc]) + cnt(rc)) | RGK_ROTATED; nbox[lc] = nb; adopt(lr, p); adopt(rc, lc); }
+                // (p itself still covers exactly its old range of the sorted order: only the node in between lost that)
+            }
+            p = parent[p];
+        }
+    }
+}
+
 // quantise one axis of up to four child boxes against the node box: the smallest power-of-two step whose outward-rounded codes
 // fit 8 bits, verified with the kernels' decode fma(q, step, p) -- the host builder's loop (rgk_host.cpp QbvhBuilder)
 __device__ void quantise_axis(const BBox* ch, int nch, int a, float p, float ext, float& step, uint8_t* qlo, uint8_t* qhi) {
@@ -158,7 +218,7 @@ __global__ void k_collapse(const int2* __restrict__ frontier, uint32_t n_front, 
             int best = -1;
             float best_area = -1.f;
             for (int i = 0; i < nch; i++)
-                if (ref[i] >= 0 && count[ref[i]] > max_leaf) { const float ar = area(box[i]); if (ar > best_area) { best_area = ar; best = i; } }
+                if (ref[i] >= 0 && ((count[ref[i]] & ~RGK_ROTATED) > max_leaf || (count[ref[i]] & RGK_ROTATED))) { const float ar = area(box[i]); if (ar > best_area) { best_area = ar; best = i; } }
             if (best < 0) break;
             const int o = ref[best];
             for (int i = best; i + 1 < nch; i++) { ref[i] = ref[i + 1]; box[i] = box[i + 1]; } // erase, then append both children (host order)
@@ -180,7 +240,7 @@ __global__ void k_collapse(const int2* __restrict__ frontier, uint32_t n_front, 
             if (i < nch) {
                 const int r = ref[i];
                 if (r < 0) code = (int)~((((uint32_t)~r) << 4) | 0u);                               // one reference
-                else if (count[r] <= max_leaf) code = (int)~((first[r] << 4) | (count[r] - 1u));      // a small subtree: its range of the sorted order
+                else if (count[r] <= max_leaf) code = (int)~((first[r] << 4) | (count[r] - 1u));      // a small, unrotated subtree: its range of the sorted order
                 else {
                     const uint32_t idx = atomicAdd(n_out, 1u);
                     const uint32_t slot = atomicAdd(n_next, 1u);
@@ -195,9 +255,127 @@ __global__ void k_collapse(const int2* __restrict__ frontier, uint32_t n_front, 
 }
 
 __global__ void k_gather_recs(const unsigned long long* __restrict__ keys, uint32_t n, const RgkBuildPrim* __restrict__ prims,
-                              const TriIsect* __restrict__ recs, TriIsect* __restrict__ leaf_recs) {
-    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
-        leaf_recs[k] = recs[prims[(uint32_t)(keys[k] & 0xffffffffull)].tri];
+                              const TriIsect* __restrict__ recs, TriIsect* __restrict__ leaf_recs, float4* __restrict__ leaf_pb) {
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const RgkBuildPrim p = prims[(uint32_t)(keys[k] & 0xffffffffull)];
+        leaf_recs[k] = recs[p.tri];
+        leaf_pb[k] = make_float4(p.pb[0], p.pb[1], p.pb[2], p.pb[3]);
+    }
+}
+
+// ------------------------------------------------------------------ refit: moved vertices, same triangles, same tree
+// The intersection record of one reference from the triangle's (new) vertices -- operation for operation what rgk_scene_create
+// computes on the host (Triangle::CalculatePlane, src/primitives.cpp:24-36, and the per-triangle differences TestIntersection
+// would recompute): same IEEE operations in the same order, no contraction, so a refitted scene holds the bits a fresh one would.
+__global__ void k_refit_recs(const float* __restrict__ vertices, const uint32_t* __restrict__ idx, const float4* __restrict__ leaf_pb, uint32_t n_refs,
+                             TriIsect* __restrict__ recs, BBox* __restrict__ refbox) {
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_refs; k += gridDim.x * blockDim.x) {
+        const uint32_t tri = recs[k].tri;
+        float v[3][3];
+        for (int c = 0; c < 3; c++) { const uint32_t vi = idx[3 * tri + c]; for (int a = 0; a < 3; a++) v[c][a] = vertices[3 * (size_t)vi + a]; }
+        const float d0[3] = {v[1][0] - v[0][0], v[1][1] - v[0][1], v[1][2] - v[0][2]}, d1[3] = {v[2][0] - v[0][0], v[2][1] - v[0][1], v[2][2] - v[0][2]};
+        // crossv(d1, d0), normv, -dotv(n, v0): rgk_host.cpp's helpers spelled out
+        const float cx = d1[1] * d0[2] - d0[1] * d1[2], cy = d1[2] * d0[0] - d0[2] * d1[0], cz = d1[0] * d0[1] - d0[0] * d1[1];
+        const float tx = cx * cx, ty = cy * cy, tz = cz * cz;
+        const float inv = 1.0f / __builtin_sqrtf(tx + ty + tz);
+        const float nx = cx * inv, ny = cy * inv, nz = cz * inv;
+        const float ux = nx * v[0][0], uy = ny * v[0][1], uz = nz * v[0][2];
+        TriIsect r;
+        r.n[0] = nx; r.n[1] = ny; r.n[2] = nz; r.d = -(ux + uy + uz);
+        int i1, i2;
+        const float ax = fabsf(nx), ay = fabsf(ny), az = fabsf(nz);
+        if (ax > ay && ax > az) { i1 = 1; i2 = 2; }
+        else if (ay > az) { i1 = 0; i2 = 2; }
+        else { i1 = 0; i2 = 1; }
+        r.v0a = v[0][i1]; r.v0b = v[0][i2];
+        r.q1x = v[1][i1] - v[0][i1]; r.q1y = v[1][i2] - v[0][i2];
+        r.q2x = v[2][i1] - v[0][i1]; r.q2y = v[2][i2] - v[0][i2];
+        r.axes = (uint32_t)i1 | ((uint32_t)i2 << 2);
+        r.tri = tri;
+        recs[k] = r;
+        BBox b; // the whole triangle's box ...
+        for (int a = 0; a < 3; a++) { b.mn[a] = fminf(v[0][a], fminf(v[1][a], v[2][a])); b.mx[a] = fmaxf(v[0][a], fmaxf(v[1][a], v[2][a])); }
+        // ... or, for one of the pieces a large triangle was split into at build time, the box of that piece: a triangle moves
+        // affinely, so the piece is still {v0 + b (v1 - v0) + c (v2 - v0)} over its old parameter box -- a parallelogram whose four
+        // corners bound it (widened by a few ulps of the coordinates: the corners are rounded)
+        const float4 pb = leaf_pb[k];
+        if (!(pb.x == 0.f && pb.y == 1.f && pb.z == 0.f && pb.w == 1.f))
+            for (int a = 0; a < 3; a++) {
+                const float e1 = v[1][a] - v[0][a], e2 = v[2][a] - v[0][a];
+                const float c00 = v[0][a] + pb.x * e1 + pb.z * e2, c10 = v[0][a] + pb.y * e1 + pb.z * e2, c01 = v[0][a] + pb.x * e1 + pb.w * e2, c11 = v[0][a] + pb.y * e1 + pb.w * e2;
+                const float m = 4e-6f * (fabsf(v[0][a]) + fabsf(e1) + fabsf(e2));
+                b.mn[a] = fmaxf(b.mn[a], fminf(fminf(c00, c10), fminf(c01, c11)) - m);
+                b.mx[a] = fminf(b.mx[a], fmaxf(fmaxf(c00, c10), fmaxf(c01, c11)) + m);
+            }
+        refbox[k] = b;
+    }
+}
+// the three normals / tangents of every triangle's shading record from the (new) per-vertex arrays; uvs and material stay
+__global__ void k_refit_shade(const float* __restrict__ normals, const float* __restrict__ tangents, const uint32_t* __restrict__ idx, uint32_t n_tris,
+                              TriShade* __restrict__ shade) {
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_tris; t += gridDim.x * blockDim.x)
+        for (int c = 0; c < 3; c++) {
+            const uint32_t vi = idx[3 * t + c];
+            for (int a = 0; a < 3; a++) {
+                if (normals) shade[t].q[c][a] = normals[3 * (size_t)vi + a];
+                if (tangents) shade[t].q[3 + c][a] = tangents[3 * (size_t)vi + a];
+            }
+        }
+}
+// who is whose parent in the 4-wide tree, and how many inner children each node waits for
+__global__ void k_qbvh_parents(const QNode* __restrict__ nodes, uint32_t n_nodes, int* __restrict__ parent, int* __restrict__ n_inner) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes; i += gridDim.x * blockDim.x) {
+        int inner = 0;
+        for (int c = 0; c < 4; c++) { const int ch = nodes[i].child[c]; if (ch >= 0 && ch != RGK_QNODE_EMPTY) { parent[ch] = (int)i; inner++; } }
+        n_inner[i] = inner;
+        if (i == 0) parent[0] = -1;
+    }
+}
+// bottom-up: a node whose inner children are all done recomputes its child boxes (leaves: the references' boxes; inner: the
+// child's own new box), its own box, and the 8-bit codes -- then reports to its parent; the last child to report takes the parent
+__global__ void k_qbvh_refit(QNode* __restrict__ nodes, uint32_t n_nodes, const int* __restrict__ parent, const int* __restrict__ n_inner,
+                             int* __restrict__ arrived, const BBox* __restrict__ refbox, BBox* __restrict__ nbox, float pad) {
+    for (uint32_t start = blockIdx.x * blockDim.x + threadIdx.x; start < n_nodes; start += gridDim.x * blockDim.x) {
+        if (n_inner[start] != 0) continue;
+        int i = (int)start;
+        for (;;) {
+            QNode q = nodes[i];
+            BBox ch[4];
+            int slot[4], nch = 0;
+            for (int c = 0; c < 4; c++) {
+                const int code = q.child[c];
+                if (code == RGK_QNODE_EMPTY) continue;
+                BBox b;
+                if (code >= 0) b = nbox[code];
+                else {
+                    const uint32_t u = ~(uint32_t)code, first = u >> 4, cnt = (u & 15u) + 1u;
+                    b = refbox[first];
+                    for (uint32_t k = 1; k < cnt; k++) b = unite(b, refbox[first + k]);
+                    for (int a = 0; a < 3; a++) { b.mn[a] -= pad; b.mx[a] += pad; }
+                }
+                ch[nch] = b; slot[nch] = c; nch++;
+            }
+            BBox nb = ch[0];
+            for (int k = 1; k < nch; k++) nb = unite(nb, ch[k]);
+            nbox[i] = nb;
+            uint8_t qlo[3][4], qhi[3][4];
+            float step[3];
+            for (int a = 0; a < 3; a++) quantise_axis(ch, nch, a, nb.mn[a], nb.mx[a] - nb.mn[a], step[a], qlo[a], qhi[a]);
+            for (int a = 0; a < 3; a++) {
+                q.p[a] = nb.mn[a];
+                for (int c = 0; c < 4; c++) { q.qlo[a][c] = 255; q.qhi[a][c] = 0; }
+                for (int k = 0; k < nch; k++) { q.qlo[a][slot[k]] = qlo[a][k]; q.qhi[a][slot[k]] = qhi[a][k]; }
+            }
+            q.sx = step[0]; q.sy = step[1]; q.sz = step[2];
+            nodes[i] = q;
+            const int p = parent[i];
+            if (p < 0) break;
+            __threadfence();
+            if (atomicAdd(&arrived[p], 1) + 1 < n_inner[p]) break; // a sibling is not done yet: its thread takes the parent
+            __threadfence();
+            i = p;
+        }
+    }
 }
 
 template <typename T>
@@ -209,10 +387,28 @@ struct Tmp { // device scratch freed on scope exit
 
 } // namespace
 
+#define BCHK_(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { *err = hipGetErrorString(e_); return e_ == hipErrorOutOfMemory ? -3 : -2; } } while (0)
+int rgk_refit_bvh4_device(hipStream_t st, uint32_t n_refs, uint32_t n_nodes, uint32_t n_tris, const float* d_vertices, const float* d_normals, const float* d_tangents,
+                          const uint32_t* d_idx, const float4* d_leaf_pb, float pad, TriIsect* d_leaf_recs, QNode* d_nodes, TriShade* d_shade, const char** err) {
+    *err = "";
+    Tmp<BBox> refbox, nbox;
+    Tmp<int> parent, n_inner, arrived;
+    BCHK_(refbox.alloc(n_refs)); BCHK_(nbox.alloc(n_nodes)); BCHK_(parent.alloc(n_nodes)); BCHK_(n_inner.alloc(n_nodes)); BCHK_(arrived.alloc(n_nodes));
+    BCHK_(hipMemsetAsync(arrived.p, 0, (size_t)n_nodes * sizeof(int), st));
+    const int gr = (int)std::min<uint32_t>((n_refs + 255) / 256, 256 * 16), gn = (int)std::min<uint32_t>((n_nodes + 255) / 256, 256 * 16);
+    k_refit_recs<<<gr, 256, 0, st>>>(d_vertices, d_idx, d_leaf_pb, n_refs, d_leaf_recs, refbox.p);
+    if (d_normals || d_tangents) k_refit_shade<<<(int)std::min<uint32_t>((n_tris + 255) / 256, 256 * 16), 256, 0, st>>>(d_normals, d_tangents, d_idx, n_tris, d_shade);
+    k_qbvh_parents<<<gn, 256, 0, st>>>(d_nodes, n_nodes, parent.p, n_inner.p);
+    k_qbvh_refit<<<gn, 256, 0, st>>>(d_nodes, n_nodes, parent.p, n_inner.p, arrived.p, refbox.p, nbox.p, pad);
+    BCHK_(hipStreamSynchronize(st));
+    BCHK_(hipGetLastError());
+    return 0;
+}
+
 #define BCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { *err = hipGetErrorString(e_); return e_ == hipErrorOutOfMemory ? -3 : -2; } } while (0)
 
 int rgk_build_bvh4_device(hipStream_t st, const RgkBuildPrim* h_prims, uint32_t n, const float smin[3], const float smax[3], float pad,
-                          uint32_t max_leaf, const TriIsect* d_recs, QNode* d_nodes, TriIsect* d_leaf_recs, uint32_t* n_nodes,
+                          uint32_t max_leaf, int rotate, const TriIsect* d_recs, QNode* d_nodes, TriIsect* d_leaf_recs, float4* d_leaf_pb, uint32_t* n_nodes,
                           uint32_t* n_levels, const char** err) {
     *err = "";
     if (n < 2 || n <= max_leaf) { *err = "too few references for the device build"; return -5; }
@@ -241,8 +437,13 @@ int rgk_build_bvh4_device(hipStream_t st, const RgkBuildPrim* h_prims, uint32_t 
     }
     BCHK(hipMemsetAsync(arrived.p, 0, (size_t)n * sizeof(int), st));
     k_hierarchy<<<grid, 256, 0, st>>>(keys_sorted.p, (int)n, left.p, right.p, parent.p, leaf_parent.p, first.p);
-    k_refit<<<grid, 256, 0, st>>>(prims.p, keys_sorted.p, (int)n, pad, left.p, right.p, parent.p, leaf_parent.p, arrived.p, nbox.p, count.p);
-    k_gather_recs<<<grid, 256, 0, st>>>(keys_sorted.p, n, prims.p, d_recs, d_leaf_recs);
+    BCHK(hipMemsetAsync(count.p, 0, (size_t)n * sizeof(uint32_t), st));
+    for (int pass = 0; pass < rotate; pass++) { // each pass: the whole tree bottom-up, one rotation per node at most
+        if (pass) BCHK(hipMemsetAsync(arrived.p, 0, (size_t)n * sizeof(int), st));
+        k_refit_rotate<<<grid, 256, 0, st>>>(prims.p, keys_sorted.p, (int)n, pad, left.p, right.p, parent.p, leaf_parent.p, arrived.p, nbox.p, count.p);
+    }
+    if (!rotate) k_refit<<<grid, 256, 0, st>>>(prims.p, keys_sorted.p, (int)n, pad, left.p, right.p, parent.p, leaf_parent.p, arrived.p, nbox.p, count.p);
+    k_gather_recs<<<grid, 256, 0, st>>>(keys_sorted.p, n, prims.p, d_recs, d_leaf_recs, d_leaf_pb);
     // collapse, level by level.  ctr[0] = nodes allocated, ctr[1] = next frontier length
     uint32_t h[2] = {1u, 0u};
     BCHK(hipMemcpyAsync(ctr.p, h, sizeof(h), hipMemcpyHostToDevice, st));

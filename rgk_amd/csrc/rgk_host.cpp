@@ -68,6 +68,10 @@ inline float comp(V3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
 struct Prim {
     float bmin[3], bmax[3], c[3];
     uint32_t tri;
+    uint32_t ref;  // this reference's number (prims are shuffled by the builders; the leaf order lists these)
+    float pb[4];   // the piece of the triangle this reference stands for, as a box in the triangle's own coordinates: P = v0 + b (v1 - v0) + c (v2 - v0)
+                   // with b in [pb[0], pb[1]], c in [pb[2], pb[3]] -- (0, 1, 0, 1): the whole triangle.  A moved triangle maps its pieces
+                   // affinely, so rgk_scene_refit re-boxes a reference from these four numbers instead of from the whole triangle
 };
 struct Box {
     float mn[3], mx[3];
@@ -91,6 +95,22 @@ struct RefSplitter {
     float lmax;
     size_t budget; // extra references still allowed
     std::vector<Prim>* out;
+    double tv[3][3]; // the triangle being split (for the pieces' parameter boxes)
+    void param_box(const std::vector<P3>& poly, float pb[4]) const {
+        double e1[3], e2[3], a11 = 0, a12 = 0, a22 = 0;
+        for (int k = 0; k < 3; k++) { e1[k] = tv[1][k] - tv[0][k]; e2[k] = tv[2][k] - tv[0][k]; a11 += e1[k] * e1[k]; a12 += e1[k] * e2[k]; a22 += e2[k] * e2[k]; }
+        const double det = a11 * a22 - a12 * a12;
+        double b0 = 1, b1 = 0, c0 = 1, c1 = 0;
+        if (!(det > 0)) { pb[0] = 0.f; pb[1] = 1.f; pb[2] = 0.f; pb[3] = 1.f; return; }
+        for (const P3& v : poly) {
+            double r1 = 0, r2 = 0;
+            for (int k = 0; k < 3; k++) { const double w = v.x[k] - tv[0][k]; r1 += e1[k] * w; r2 += e2[k] * w; }
+            const double b = (a22 * r1 - a12 * r2) / det, c = (a11 * r2 - a12 * r1) / det;
+            b0 = std::min(b0, b); b1 = std::max(b1, b); c0 = std::min(c0, c); c1 = std::max(c1, c);
+        }
+        const double pad = 1e-5; // (the solve's rounding; the pieces overlap by this much)
+        pb[0] = (float)std::max(0.0, b0 - pad); pb[1] = (float)std::min(1.0, b1 + pad); pb[2] = (float)std::max(0.0, c0 - pad); pb[3] = (float)std::min(1.0, c1 + pad);
+    }
     static void clip(const std::vector<P3>& in, int ax, double plane, bool keep_below, std::vector<P3>& res) {
         res.clear();
         const size_t n = in.size();
@@ -124,6 +144,8 @@ struct RefSplitter {
         if (!(p.bmax[ax] - p.bmin[ax] > lmax) || depth >= 12 || budget == 0 || poly.size() < 3) {
             for (int a = 0; a < 3; a++) p.c[a] = 0.5f * (p.bmin[a] + p.bmax[a]);
             p.tri = tri;
+            p.ref = (uint32_t)out->size();
+            if (depth == 0) { p.pb[0] = 0.f; p.pb[1] = 1.f; p.pb[2] = 0.f; p.pb[3] = 1.f; } else param_box(poly, p.pb);
             out->push_back(p);
             return;
         }
@@ -143,7 +165,7 @@ struct RefSplitter {
 struct BvhBuilder {
     std::vector<Prim>& prims;
     std::vector<BvhNode> nodes;
-    std::vector<uint32_t> order; // triangle ids in leaf order
+    std::vector<uint32_t> order; // reference numbers (Prim::ref) in leaf order
     uint32_t max_depth = 0;
     float pad;
     static constexpr int NBINS = 16;
@@ -156,7 +178,7 @@ struct BvhBuilder {
 
     int make_leaf(size_t b, size_t e) {
         uint32_t first = order.size();
-        for (size_t i = b; i < e; i++) order.push_back(prims[i].tri);
+        for (size_t i = b; i < e; i++) order.push_back(prims[i].ref);
         uint32_t cnt = (uint32_t)(e - b);
         return (int)~((first << 4) | (cnt - 1));
     }
@@ -496,6 +518,13 @@ struct rgk_scene {
     DevBuf<DevScene> self;    // device-resident copy of `dev` (DevScene::self)
     DevBuf<uint32_t> generic; // queue indices left to the generic-BxDF shade launch
     DevBuf<TexRef> texrefs;   // one TexRef per descriptor texture (rgk_texture_sample)
+    // what rgk_scene_refit needs of the descriptor after rgk_scene_create has returned
+    DevBuf<uint32_t> d_idx;   // tri_indices on the device
+    DevBuf<float4> leaf_pb;   // per leaf reference: its piece of the triangle in the triangle's own coordinates (Prim::pb)
+    std::vector<uint32_t> h_idx, h_tri_mat, h_areal_off, h_areal_tris;
+    std::vector<rgk_material> h_mats;
+    std::vector<float> h_normals;
+    uint32_t n_vertices = 0, n_triangles = 0, n_refs = 0, n_nodes = 0;
     uint32_t n_textures = 0, n_materials = 0;
     DevBuf<DevHaltonDim> hdims;
     DevBuf<uint16_t> hperm;
@@ -535,7 +564,7 @@ struct rgk_scene {
         if (h_stage) (void)hipHostFree(h_stage);
         nodes.release(); tris.release(); tri_shade.release(); materials.release(); texels8.release(); luts.release();
         texels.release(); pointlights.release(); areal.release(); areal_tris.release(); ltc.release(); self.release(); ovf.release();
-        hdims.release(); hperm.release(); texrefs.release();
+        hdims.release(); hperm.release(); texrefs.release(); d_idx.release(); leaf_pb.release();
         for (int i = 0; i < 2; i++) { rayA[i].release(); rayB[i].release(); }
         hit.release(); thr.release(); tot.release(); shA.release(); shB.release(); shC.release(); pixsum.release();
         light.release(); generic.release(); htab.release(); lstart.release(); lv.release(); hitlist.release(); lvmask.release(); connlist.release(); conn.release(); jobs.release(); rads.release();
@@ -739,6 +768,55 @@ static void debug_desc(const rgk_scene_desc* d) {
 #ifndef RGK_SAMPLE_GROUP_DEFAULT
 #define RGK_SAMPLE_GROUP_DEFAULT 3 // 8 samples of a pixel side by side: swept 0..6 on the Sponza proxy (154.2, -, 149.6, 148.4, 148.1, 150.3, 150.0 ms per round)
 #endif
+// Scene::Commit's areal-light tables (src/scene.cpp:323-344): per emissive object its triangles sorted by area (descending), the
+// total area, power = area * (r + g + b).  Used by rgk_scene_create and, for moved vertices, by rgk_scene_refit.
+static void build_areal_tables(const float* vertices, const float* normals, const uint32_t* tri_indices, const uint32_t* tri_material, const rgk_material* materials,
+                               uint32_t n_areal, const uint32_t* areal_offsets, const uint32_t* areal_tris, std::vector<DevArealLight>& als,
+                               std::vector<DevArealTri>& ats, float& total_areal) {
+    auto vert = [&](uint32_t i) { return V3{vertices[3 * i], vertices[3 * i + 1], vertices[3 * i + 2]}; };
+    als.clear(); ats.clear(); total_areal = 0.f;
+    for (uint32_t i = 0; i < n_areal; i++) {
+        uint32_t b = areal_offsets[i], e = areal_offsets[i + 1];
+        if (e <= b) continue;
+        std::vector<std::pair<float, uint32_t>> twa;
+        float total_area = 0.f;
+        for (uint32_t j = b; j < e; j++) {
+            uint32_t t = areal_tris[j];
+            V3 A = vert(tri_indices[3 * t]), B = vert(tri_indices[3 * t + 1]), C = vert(tri_indices[3 * t + 2]);
+            V3 c = crossv(sub(A, B), sub(C, B)); // Triangle::GetArea primitives.cpp:38-45
+            float area = 0.5f * std::sqrt(dotv(c, c));
+            twa.push_back({area, t});
+            total_area += area;
+        }
+        const rgk_material& m0 = materials[tri_material[twa[0].second]];
+        std::sort(twa.rbegin(), twa.rend()); // descending by (area, index)
+        DevArealLight al{};
+        al.total_area = total_area;
+        for (int k = 0; k < 3; k++) al.emission[k] = m0.emission[k];
+        al.power = total_area * (m0.emission[0] + m0.emission[1] + m0.emission[2]);
+        al.first = (uint32_t)ats.size();
+        al.count = (uint32_t)twa.size();
+        for (auto& p : twa) {
+            DevArealTri at{};
+            at.area = p.first; at.tri = p.second; at.light = (uint32_t)als.size();
+            uint32_t ia = tri_indices[3 * p.second], ib = tri_indices[3 * p.second + 1], ic = tri_indices[3 * p.second + 2];
+            for (int k = 0; k < 3; k++) {
+                at.a[k] = vertices[3 * ia + k]; at.b[k] = vertices[3 * ib + k]; at.c[k] = vertices[3 * ic + k];
+                at.normal_a[k] = normals[3 * ia + k];
+            }
+            ats.push_back(at);
+        }
+        total_areal += al.power;
+        als.push_back(al);
+    }
+}
+
+#ifndef RGK_BUILD_AUTO_DEVICE_REFS
+#define RGK_BUILD_AUTO_DEVICE_REFS 500000
+#endif
+#ifndef RGK_LBVH_ROTATE_PASSES
+#define RGK_LBVH_ROTATE_PASSES 4
+#endif
 int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
     if (!out) return fail(RGK_ERR_INVALID, "null output pointer");
     *out = nullptr;
@@ -819,12 +897,16 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
                 p.c[a] = 0.5f * (p.bmin[a] + p.bmax[a]);
             }
             p.tri = i;
+            p.pb[0] = 0.f; p.pb[1] = 1.f; p.pb[2] = 0.f; p.pb[3] = 1.f;
             if (splitter.lmax > 0.f) {
                 std::vector<RefSplitter::P3> poly(3);
                 for (int a = 0; a < 3; a++) { poly[0].x[a] = comp(v0, a); poly[1].x[a] = comp(v1, a); poly[2].x[a] = comp(v2, a); }
+                for (int c = 0; c < 3; c++) for (int a = 0; a < 3; a++) splitter.tv[c][a] = poly[c].x[a];
                 splitter.emit(poly, p.bmin, p.bmax, i, 0);
-            } else
+            } else {
+                p.ref = (uint32_t)prims.size();
                 prims.push_back(p);
+            }
         }
     }
     // ---- accelerator
@@ -832,21 +914,34 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
     if (prims.size() >= (1u << 25)) return fail(RGK_ERR_UNSUPPORTED, "too many triangles (32-bit byte offsets into the triangle tables: < 2^25)");
     std::vector<QNode> qnodes;
     std::vector<TriIsect> leaf_recs;
+    std::vector<float4> leaf_pb; // per leaf reference: its piece of the triangle in the triangle's own coordinates (Prim::pb), for rgk_scene_refit
+    std::vector<uint32_t> ref_tri(prims.size());
+    std::vector<float4> ref_pb(prims.size());
+    for (const Prim& p : prims) { ref_tri[p.ref] = p.tri; ref_pb[p.ref] = make_float4(p.pb[0], p.pb[1], p.pb[2], p.pb[3]); }
     uint32_t max_depth = 0, max_stack = 0, n_nodes = 0, n_refs = (uint32_t)prims.size();
     bool on_device = false;
-    const int MAX_LEAF_DEV = 4;
-    if ((d->build_flags & RGK_BUILD_DEVICE) && prims.size() > (size_t)MAX_LEAF_DEV) {
+    // leaves of the device build: at most 2 references (Morton-adjacent triangles make loose leaves: with 4, a ray tests twice the
+    // triangles the host tree makes it test -- measured with 1 / 2 / 3 / 4 on the 1.05 M-triangle scene, closest-hit + shadow ms of
+    // a round: 7.69 / 7.48 / 7.59 / 8.10, host SAH 7.36: tools/gpu_lbvh_rotate_sweep.py)
+    int MAX_LEAF_DEV = 2;
+    if (const char* e = std::getenv("RGK_BVH_MAXLEAF_DEV")) MAX_LEAF_DEV = std::min(16, std::max(1, std::atoi(e)));
+    // which builder: asked for explicitly, or (RGK_BUILD_AUTO) by size -- from half a million references on, the host's SAH build
+    // takes seconds (1.5 s at 1.05 M) where the device build takes 0.15 s and traces within 2 % of it
+    const bool want_device = (d->build_flags & RGK_BUILD_DEVICE) || (!(d->build_flags & RGK_BUILD_HOST_SAH) && prims.size() >= (size_t)RGK_BUILD_AUTO_DEVICE_REFS);
+    if (want_device && prims.size() > (size_t)MAX_LEAF_DEV) {
         // LBVH on the GPU (rgk_build.hip): the references go up, nodes and leaf-ordered records stay on the device
         std::vector<RgkBuildPrim> bp(prims.size());
         for (size_t i = 0; i < prims.size(); i++) {
             for (int a = 0; a < 3; a++) { bp[i].bmin[a] = prims[i].bmin[a]; bp[i].bmax[a] = prims[i].bmax[a]; }
             bp[i].tri = prims[i].tri;
+            for (int a = 0; a < 4; a++) bp[i].pb[a] = prims[i].pb[a];
         }
         DevBuf<TriIsect> d_recs;
-        if ((rc = d_recs.upload(recs)) || (rc = s->nodes.alloc(prims.size())) || (rc = s->tris.alloc(prims.size()))) { d_recs.release(); return rc; }
+        if ((rc = d_recs.upload(recs)) || (rc = s->nodes.alloc(prims.size())) || (rc = s->tris.alloc(prims.size())) || (rc = s->leaf_pb.alloc(prims.size()))) { d_recs.release(); return rc; }
         uint32_t levels = 0;
         const char* err = "";
-        rc = rgk_build_bvh4_device(s->stream, bp.data(), n_refs, mn, mx, eps, (uint32_t)MAX_LEAF_DEV, d_recs.p, s->nodes.p, s->tris.p, &n_nodes, &levels, &err);
+        const char* rot = std::getenv("RGK_LBVH_ROTATE"); // passes of the rotation step; 0: the plain LBVH (for comparisons)
+        rc = rgk_build_bvh4_device(s->stream, bp.data(), n_refs, mn, mx, eps, (uint32_t)MAX_LEAF_DEV, rot ? std::max(0, std::min(32, std::atoi(rot))) : RGK_LBVH_ROTATE_PASSES, d_recs.p, s->nodes.p, s->tris.p, s->leaf_pb.p, &n_nodes, &levels, &err);
         d_recs.release();
         if (rc) return fail(rc, "device BVH build: %s", err);
         max_depth = levels;
@@ -876,7 +971,8 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
         }
         nodes.swap(bb.nodes);
         leaf_recs.reserve(bb.order.size());
-        for (uint32_t t : bb.order) leaf_recs.push_back(recs[t]);
+        leaf_pb.reserve(bb.order.size());
+        for (uint32_t r : bb.order) { leaf_recs.push_back(recs[ref_tri[r]]); leaf_pb.push_back(ref_pb[r]); }
         QbvhBuilder qb(nodes);
         qb.out.reserve(nodes.size() / 2 + 1);
         if (qb.collapse(0, 0, 0) != 0) return fail(RGK_ERR_DEVICE, "internal: QBVH root is not node 0");
@@ -1047,48 +1143,25 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
     std::vector<DevArealLight> als;
     std::vector<DevArealTri> ats;
     float total_areal = 0.f;
-    for (uint32_t i = 0; i < d->n_areal_lights; i++) {
-        uint32_t b = d->areal_offsets[i], e = d->areal_offsets[i + 1];
-        if (e <= b) continue;
-        std::vector<std::pair<float, uint32_t>> twa;
-        float total_area = 0.f;
-        for (uint32_t j = b; j < e; j++) {
-            uint32_t t = d->areal_tris[j];
-            V3 A = vert(d->tri_indices[3 * t]), B = vert(d->tri_indices[3 * t + 1]), C = vert(d->tri_indices[3 * t + 2]);
-            V3 c = crossv(sub(A, B), sub(C, B)); // Triangle::GetArea primitives.cpp:38-45
-            float area = 0.5f * std::sqrt(dotv(c, c));
-            twa.push_back({area, t});
-            total_area += area;
-        }
-        const rgk_material& m0 = d->materials[d->tri_material[twa[0].second]];
-        std::sort(twa.rbegin(), twa.rend()); // descending by (area, index)
-        DevArealLight al{};
-        al.total_area = total_area;
-        for (int k = 0; k < 3; k++) al.emission[k] = m0.emission[k];
-        al.power = total_area * (m0.emission[0] + m0.emission[1] + m0.emission[2]);
-        al.first = (uint32_t)ats.size();
-        al.count = (uint32_t)twa.size();
-        for (auto& p : twa) {
-            DevArealTri at{};
-            at.area = p.first; at.tri = p.second; at.light = (uint32_t)als.size();
-            uint32_t ia = d->tri_indices[3 * p.second], ib = d->tri_indices[3 * p.second + 1], ic = d->tri_indices[3 * p.second + 2];
-            for (int k = 0; k < 3; k++) {
-                at.a[k] = d->vertices[3 * ia + k]; at.b[k] = d->vertices[3 * ib + k]; at.c[k] = d->vertices[3 * ic + k];
-                at.normal_a[k] = d->normals[3 * ia + k];
-            }
-            ats.push_back(at);
-        }
-        total_areal += al.power;
-        als.push_back(al);
-    }
+    build_areal_tables(d->vertices, d->normals, d->tri_indices, d->tri_material, d->materials, d->n_areal_lights, d->areal_offsets, d->areal_tris, als, ats, total_areal);
     std::vector<DevHaltonDim> hd;
     std::vector<uint16_t> hp;
     build_halton(hd, hp);
 
     // ---- upload
     s->n_textures = d->n_textures; s->n_materials = d->n_materials;
+    s->n_vertices = d->n_vertices; s->n_triangles = nt; s->n_refs = n_refs; s->n_nodes = n_nodes;
+    s->h_idx.assign(d->tri_indices, d->tri_indices + 3 * (size_t)nt);
+    s->h_tri_mat.assign(d->tri_material, d->tri_material + nt);
+    s->h_mats.assign(d->materials, d->materials + d->n_materials);
+    s->h_normals.assign(d->normals, d->normals + 3 * (size_t)d->n_vertices);
+    if (d->n_areal_lights) {
+        s->h_areal_off.assign(d->areal_offsets, d->areal_offsets + d->n_areal_lights + 1);
+        s->h_areal_tris.assign(d->areal_tris, d->areal_tris + d->areal_offsets[d->n_areal_lights]);
+    }
+    if ((rc = s->d_idx.upload(s->h_idx))) return rc;
     if ((rc = s->texrefs.upload(trefs))) return rc;
-    if (!on_device && ((rc = s->nodes.upload(qnodes)) || (rc = s->tris.upload(leaf_recs)))) return rc;
+    if (!on_device && ((rc = s->nodes.upload(qnodes)) || (rc = s->tris.upload(leaf_recs)) || (rc = s->leaf_pb.upload(leaf_pb)))) return rc;
     if ((rc = s->tri_shade.upload(tsh)) ||
         (rc = s->materials.upload(mats)) || (rc = s->texels.upload(pool)) || (rc = s->texels8.upload(pool8)) ||
         (rc = s->luts.upload(luts)) || (rc = s->pointlights.upload(pls)) || (rc = s->areal.upload(als)) ||
@@ -1130,6 +1203,52 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
     inf.n_float_textures = n_float_tex; inf.n_palettized_textures = n_palettized;
     guard.s = nullptr;
     *out = s;
+    return RGK_OK;
+}
+
+int rgk_scene_refit(rgk_scene* s, const float* vertices, const float* normals, const float* tangents) {
+    if (!s || !vertices) return fail(RGK_ERR_INVALID, "null argument");
+    if (s->prog_busy.load()) return fail(RGK_ERR_INVALID, "rgk_scene_refit while a round is in flight on this scene");
+    HIPCHK(hipSetDevice(s->device));
+    const uint32_t nt = s->n_triangles, nv = s->n_vertices;
+    // ---- Commit's scalars for the new positions: bounds, epsilon (scene.cpp:364-395)
+    float mn[3], mx[3];
+    for (int a = 0; a < 3; a++) { mn[a] = std::numeric_limits<float>::infinity(); mx[a] = -mn[a]; }
+    for (size_t k = 0; k < 3 * (size_t)nt; k++) {
+        const float* v = vertices + 3 * (size_t)s->h_idx[k];
+        for (int a = 0; a < 3; a++) { if (v[a] < mn[a]) mn[a] = v[a]; if (v[a] > mx[a]) mx[a] = v[a]; }
+    }
+    const float xs = mx[0] - mn[0], ys = mx[1] - mn[1], zs = mx[2] - mn[2];
+    const float diameter = std::sqrt(xs * xs + ys * ys + zs * zs);
+    const float eps = 0.00001f * diameter;
+    if (!(eps == eps) || !(diameter < std::numeric_limits<float>::infinity())) return fail(RGK_ERR_INVALID, "non-finite vertex coordinates");
+    // ---- records, shading normals / tangents, and the tree's boxes: on the device
+    int rc;
+    if ((rc = up(s->scratch_f, vertices, 3 * (size_t)nv))) return rc;
+    DevBuf<float> d_n, d_t;
+    struct Rel { DevBuf<float>&a, &b; ~Rel() { a.release(); b.release(); } } rel{d_n, d_t};
+    if (normals && (rc = up(d_n, normals, 3 * (size_t)nv))) return rc;
+    if (tangents && (rc = up(d_t, tangents, 3 * (size_t)nv))) return rc;
+    const char* err = "";
+    rc = rgk_refit_bvh4_device(s->stream, s->n_refs, s->n_nodes, nt, s->scratch_f.p, normals ? d_n.p : nullptr, tangents ? d_t.p : nullptr, s->d_idx.p, s->leaf_pb.p, eps,
+                               s->tris.p, s->nodes.p, s->tri_shade.p, &err);
+    if (rc) return fail(rc, "refit: %s", err);
+    // ---- areal-light tables (areas, positions, vertex-A normals change with the vertices)
+    if (normals) s->h_normals.assign(normals, normals + 3 * (size_t)nv);
+    std::vector<DevArealLight> als;
+    std::vector<DevArealTri> ats;
+    float total_areal = 0.f;
+    build_areal_tables(vertices, s->h_normals.data(), s->h_idx.data(), s->h_tri_mat.data(), s->h_mats.data(), (uint32_t)(s->h_areal_off.empty() ? 0 : s->h_areal_off.size() - 1),
+                       s->h_areal_off.data(), s->h_areal_tris.data(), als, ats, total_areal);
+    if ((rc = s->areal.upload(als)) || (rc = s->areal_tris.upload(ats))) return rc;
+    DevScene& ds = s->dev;
+    ds.areal = s->areal.p; ds.areal_tris = s->areal_tris.p; ds.n_areal = (uint32_t)als.size(); ds.total_areal_power = total_areal;
+    ds.epsilon = eps;
+    for (int a = 0; a < 3; a++) { ds.bb_min[a] = mn[a] - eps; ds.bb_max[a] = mx[a] + eps; }
+    if (hipMemcpy(s->self.p, &ds, sizeof(DevScene), hipMemcpyHostToDevice) != hipSuccess) return fail(RGK_ERR_DEVICE, "hipMemcpy(DevScene)");
+    s->info.epsilon = eps; s->info.total_areal_power = total_areal;
+    for (int a = 0; a < 3; a++) { s->info.bbox_min[a] = ds.bb_min[a]; s->info.bbox_max[a] = ds.bb_max[a]; }
+    s->entry_key = 0; s->entry_n = 0; s->entry_capped = 0; s->lentry_done = 0; // per-frame lists were made for the old boxes
     return RGK_OK;
 }
 

@@ -71,6 +71,12 @@ class Scene:
             capi.check(self.lib, self.lib.rgk_scene_set_tuning(self.h, k.encode(), float(v)))
         return self
 
+    def refit(self, vertices, normals=None, tangents=None):
+        """rgk_scene_refit: moved vertices, same triangles -- records, epsilon, box, light tables recomputed, the tree refit."""
+        arr = [None if a is None else np.ascontiguousarray(a, dtype=np.float32) for a in (vertices, normals, tangents)]
+        capi.check(self.lib, self.lib.rgk_scene_refit(self.h, *[None if a is None else a.ctypes.data for a in arr]))
+        return self
+
     def info(self):
         i = capi.SceneInfo()
         capi.check(self.lib, self.lib.rgk_scene_get_info(self.h, C.byref(i)))

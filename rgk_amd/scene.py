@@ -586,7 +586,8 @@ class SceneBuilder:
         bek = np.fromfile(os.path.join(HERE, "data", "ltc_beckmann.f32"), dtype=f32)
         assert ggx.size == 5 * 4096 and bek.size == 5 * 4096
         d.ltc_ggx, d.ltc_beckmann = fp(ggx), fp(bek)
-        d.build_flags = capi.BUILD_DEVICE if os.environ.get("RGK_BVH_BUILD", "").lower() in ("gpu", "device") else getattr(self, "build_flags", capi.BUILD_HOST_SAH)
+        env = os.environ.get("RGK_BVH_BUILD", "").lower()  # gpu | host: force a builder (default: by size, RGK_BUILD_AUTO)
+        d.build_flags = capi.BUILD_DEVICE if env in ("gpu", "device") else (capi.BUILD_HOST_SAH if env in ("host", "cpu", "sah") else getattr(self, "build_flags", capi.BUILD_AUTO))
         keep += [mats, texs, pls, offs, tris, ggx, bek]
         d._keep = keep  # the descriptor owns its buffers too: `builder.to_desc()` on a temporary builder stays valid
         return d
