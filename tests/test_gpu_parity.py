@@ -328,6 +328,13 @@ def test_sponza_proxy_image_parity(rd, oracle, sponza_small):
     assert rel <= 5e-3 and within >= 0.999, (rel, within)
     assert abs(int(kg.path_rays) - int(ko.path_rays)) <= 1e-4 * ko.path_rays
     assert np.isfinite(img).all()
+    # (clamping does not help: with clamp 5 the same 2.089e-3 -- the tie path carries an ordinary value, it is just an eighth of
+    # its pixel.)  The same frame at 64 spp: the path is a 64th, and SURVEY 8(d)'s 1e-3 holds at this size too
+    from rgk_amd.workloads import Workload
+    wl64 = Workload("sponza-1080p", scale=0.1, spp=64)
+    img, ref, kg, ko = render_both(rd, oracle, wl64)
+    rel, within = image_metrics(img, ref, "test_sponza_proxy_image_parity:64spp")
+    assert rel <= 1e-3 and within >= 0.999, (rel, within)
 
 
 def test_sponza4_sphere_light_clamp_russian(rd, oracle):
@@ -337,6 +344,13 @@ def test_sponza4_sphere_light_clamp_russian(rd, oracle):
     rel, within = image_metrics(img, ref, "test_sponza4_sphere_light_clamp_russian")
     assert rel <= 5e-3 and within >= 0.999, (rel, within)    # measured 2.6e-3 / 0.9998 (8 spp: see test_sponza_proxy_image_parity)
     assert img.max() <= wl.clamp * (1 + 1e-6)
+    # 64 spp of the same frame: one tie path is an eighth of what it was, and SURVEY 8(d)'s 1e-3 holds (clamp 5 is this config's own)
+    wl64 = Workload("sponza4-2160p", scale=0.04, spp=64)
+    img, ref, kg, ko = render_both(rd, oracle, wl64)
+    rel, within = image_metrics(img, ref, "test_sponza4_sphere_light_clamp_russian:64spp")
+    d = np.linalg.norm(img - ref, axis=2); r = np.linalg.norm(ref, axis=2)
+    gate = float((d <= np.maximum(1e-3 * r, 4.0 * wl64.clamp / 64)).mean())   # SURVEY 8(d)'s per-pixel gate, clamp term included (clamp 5 here)
+    assert rel <= 1e-3 and gate >= 0.999 and within >= 0.998, (rel, gate, within)   # measured 8.3e-4 / 1.0 / 0.9989 (depth 4: 14 of 13 158 pixels hold a path that went another way)
 
 
 def test_dragon_sponza_config4_small(rd, oracle):
