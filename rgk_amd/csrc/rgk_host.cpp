@@ -492,6 +492,7 @@ struct RgkTuning {
     int sample_group = -1;    // log2 of the samples of a pixel side by side in the slot order; -1: the compiled default
     size_t batch_paths = 0;   // paths per pass; 0: sized from the memory that is free
     double workspace_gb = 0;  // ... or from this many GB; 0: 96 (160 for bidirectional rounds), at most 60 % of what is free
+    bool two_lanes = false;   // experiment (measured: no gain, see render_round): the two halves of the pixel list as two passes on two streams
     bool debug_bvh = false, debug_util = false;
 };
 
@@ -499,10 +500,13 @@ struct rgk_scene {
     int device = 0;
     RgkTuning tune;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // second lane of a round (two halves of the pixel list side by side: one's launch tails under the other's launches)
+    hipEvent_t ev_prelude = nullptr; // the round's lists and tables are in place (stream2 waits for it)
     rgk_scene_info info{};
     DevScene dev{};
     RgkTraceCfg tcfg{32, 32, nullptr};
-    DevBuf<int> ovf; // traversal-stack overflow area (deep trees)
+    DevBuf<int> ovf; // traversal-stack overflow area (deep trees), one per lane
+    size_t ovf_lane = 0;
     // scene data
     DevBuf<QNode> nodes;
     DevBuf<TriIsect> tris;
@@ -570,6 +574,8 @@ struct rgk_scene {
         light.release(); generic.release(); htab.release(); lstart.release(); lv.release(); hitlist.release(); lvmask.release(); connlist.release(); conn.release(); jobs.release(); rads.release();
         nearfar.release(); counters.release(); pix_xy.release(); pix_seed.release(); tile_buf.release(); stats.release(); entry.release(); entry_cap.release(); lentry.release(); trange.release(); lbox.release();
         scratch_f.release(); scratch_u.release();
+        if (ev_prelude) (void)hipEventDestroy(ev_prelude);
+        if (stream2) (void)hipStreamDestroy(stream2);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -600,11 +606,11 @@ int ensure_workspace(rgk_scene* s, size_t paths, uint32_t reverse = 0) {
     }
     if (!rc) rc = s->light.alloc(paths);
     if (!rc) rc = s->generic.alloc(paths);
-    if (!rc) rc = s->counters.alloc(2 * RGK_CNT_TOTAL); // [0]: camera phase, [1]: light sub-path phase
+    if (!rc) rc = s->counters.alloc(4 * RGK_CNT_TOTAL); // per lane: [0] camera phase, [1] light sub-path phase
     if (!rc) rc = s->stats.alloc(8);
     if (rc) { s->batch = 0; s->batch_reverse = 0; return rc; } // some buffers are gone: the next call starts over
-    if (!s->h_counters) HIPCHK(hipHostMalloc((void**)&s->h_counters, 2 * RGK_CNT_TOTAL * sizeof(uint32_t)));
-    if (!s->h_stage) { HIPCHK(hipHostMalloc((void**)&s->h_stage, sizeof(uint32_t))); *s->h_stage = 0; }
+    if (!s->h_counters) HIPCHK(hipHostMalloc((void**)&s->h_counters, 4 * RGK_CNT_TOTAL * sizeof(uint32_t)));
+    if (!s->h_stage) { HIPCHK(hipHostMalloc((void**)&s->h_stage, 2 * sizeof(uint32_t))); s->h_stage[0] = s->h_stage[1] = 0; }
     s->batch = paths;
     s->batch_reverse = reverse;
     return 0;
@@ -831,6 +837,8 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
     s->device = device;
     struct Guard { rgk_scene* s; ~Guard() { delete s; } } guard{s};
     HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&s->ev_prelude, hipEventDisableTiming));
     {
         auto off = [](const char* name) { const char* e = std::getenv(name); return e && e[0] == '0'; };
         RgkTuning& t = s->tune;
@@ -838,6 +846,7 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
         if (const char* e = std::getenv("RGK_SAMPLE_GROUP")) t.sample_group = std::min(6, std::max(0, std::atoi(e)));
         if (const char* e = std::getenv("RGK_BATCH_PATHS")) t.batch_paths = std::max<size_t>(1024, strtoull(e, nullptr, 10));
         if (const char* e = std::getenv("RGK_WORKSPACE_GB")) t.workspace_gb = atof(e);
+        { const char* e = std::getenv("RGK_TWO_LANES"); t.two_lanes = e && e[0] == '1'; }
         t.debug_bvh = std::getenv("RGK_DEBUG_BVH") != nullptr; t.debug_util = std::getenv("RGK_DEBUG_UTIL") != nullptr;
     }
 
@@ -989,7 +998,8 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
         s->tcfg.ovf = nullptr;
         if (s->tcfg.lds < s->tcfg.stack) {
             const size_t per_lane = (size_t)std::max(need - s->tcfg.lds, 1);
-            if ((rc = s->ovf.alloc((size_t)rgk_trace_grid(s->tcfg.lds) * RGK_TRACE_BLOCK * per_lane))) return rc;
+            s->ovf_lane = (size_t)rgk_trace_grid(s->tcfg.lds) * RGK_TRACE_BLOCK * per_lane;
+            if ((rc = s->ovf.alloc(2 * s->ovf_lane))) return rc; // one area per lane of a round: two traversal launches may be in flight
             s->tcfg.ovf = s->ovf.p;
         }
     }
@@ -1262,7 +1272,7 @@ int rgk_scene_get_info(const rgk_scene* s, rgk_scene_info* out) {
 
 int rgk_scene_get_progress(const rgk_scene* s, rgk_progress* out) {
     if (!s || !out) return fail(RGK_ERR_INVALID, "null argument");
-    out->stage = s->h_stage ? *(volatile const uint32_t*)s->h_stage : 0u; out->stages = s->prog_stages.load(); out->rounds = s->prog_rounds.load(); out->busy = s->prog_busy.load();
+    out->stage = s->h_stage ? ((volatile const uint32_t*)s->h_stage)[0] + ((volatile const uint32_t*)s->h_stage)[1] : 0u; out->stages = s->prog_stages.load(); out->rounds = s->prog_rounds.load(); out->busy = s->prog_busy.load();
     out->round_pixels = s->prog_pixels.load(); out->round_paths = s->prog_paths.load();
     if (out->stage > out->stages) out->stage = out->stages;
     return RGK_OK;
@@ -1279,6 +1289,7 @@ int rgk_scene_set_tuning(rgk_scene* s, const char* key, double value) {
     else if (k == "sample_group") t.sample_group = value < 0 ? -1 : (int)std::min(6.0, value);
     else if (k == "batch_paths") t.batch_paths = value <= 0 ? 0 : std::max<size_t>(1024, (size_t)value);
     else if (k == "workspace_gb") t.workspace_gb = value <= 0 ? 0.0 : value;
+    else if (k == "two_lanes") t.two_lanes = value != 0;
     else return fail(RGK_ERR_INVALID, "unknown tuning key '%s'", key);
     // per-frame lists were made under the old switches: the next round rebuilds them
     s->entry_key = 0; s->entry_n = 0; s->entry_capped = 0; s->lentry_done = 0;
@@ -1410,14 +1421,27 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
     // paths per pass: what the card has room for now (an existing workspace counts as room); halved on an allocation failure
     size_t B = batch_paths(s->tune, R);
     if (!s->tune.batch_paths && s->batch_reverse >= R) B = std::max(B, s->batch); // (an explicit batch size is taken literally)
+    // Two lanes (an experiment, off by default: RGK_TWO_LANES=1 / rgk_scene_set_tuning "two_lanes"): a unidirectional round of
+    // shallow depth runs the two halves of its pixel list as two passes side by side on two streams, each in its own half of the
+    // workspace -- the idea being that every launch ends in a tail of waves still finishing which the other lane's launches could
+    // fill.  Measured inside one process, same bits: Sponza 1080p x 256 126.7 vs 126.9 ms per round (nothing), Cornell 1024 x 256
+    // 119.3 vs 110.4 (8 % WORSE: ten bounces of short launches, each now competing for the card) -- the launches fill the machine
+    // one at a time, as round 2 found with two processes and with two host threads.
+    const bool count_stats = (prm->flags & RGK_FLAG_COUNT_TRAVERSAL) != 0;
+    const bool track = prm->depth > 12; // measured: depth 10 loses 4 % to the read-backs, depth 40 gains 4 %
+    const bool two = s->tune.two_lanes && R == 0 && !track && !count_stats && (uint64_t)P * prm->multisample >= (1ull << 22) && P >= 4096;
     size_t npix_pass;
     uint32_t ns_pass;
+    size_t lane_cap = 0; // paths per lane = offset of the second lane in every workspace array
     for (;;) {
-        npix_pass = std::min(P, B);
-        const uint32_t ns_max = (uint32_t)std::max<size_t>(1, std::min<size_t>(prm->multisample, B / npix_pass));
+        const size_t Bl = two ? B / 2 : B; // per lane
+        npix_pass = std::min(P, Bl);
+        if (two) npix_pass = std::min(npix_pass, ((P + 1) / 2 + 1023) & ~(size_t)1023); // at least two passes: halves of the list, whole 1024-pixel tiles
+        const uint32_t ns_max = (uint32_t)std::max<size_t>(1, std::min<size_t>(prm->multisample, Bl / npix_pass));
         const uint32_t n_sample_passes = (prm->multisample + ns_max - 1) / ns_max;
         ns_pass = (prm->multisample + n_sample_passes - 1) / n_sample_passes; // equal-sized passes
-        rc = ensure_workspace(s, npix_pass * ns_pass, R);
+        lane_cap = npix_pass * ns_pass;
+        rc = ensure_workspace(s, two ? 2 * lane_cap : lane_cap, R);
         if (rc != RGK_ERR_OOM || B <= ((size_t)1 << 20)) break;
         (void)hipGetLastError();
         B /= 2;
@@ -1428,7 +1452,6 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
     DevCamera cam;
     make_camera(camera, cam);
     hipStream_t st = s->stream;
-    const bool count_stats = (prm->flags & RGK_FLAG_COUNT_TRAVERSAL) != 0;
     const bool timing = (prm->flags & RGK_FLAG_TIME_KERNELS) != 0;
     HIPCHK(hipMemsetAsync(s->stats.p, 0, 8 * sizeof(unsigned long long), st));
     struct Ev { int cls; hipEvent_t a, b; };
@@ -1469,13 +1492,14 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
     // round trip per mark)
     {
         const uint32_t n_pix_passes = (uint32_t)((P + npix_pass - 1) / npix_pass), n_s_passes = (prm->multisample + ns_pass - 1) / ns_pass;
-        *(volatile uint32_t*)s->h_stage = 0; s->prog_stages = n_pix_passes * n_s_passes * std::max(1u, prm->depth);
+        ((volatile uint32_t*)s->h_stage)[0] = 0; ((volatile uint32_t*)s->h_stage)[1] = 0; s->prog_stages = n_pix_passes * n_s_passes * std::max(1u, prm->depth);
         s->prog_pixels = P; s->prog_paths = (uint64_t)P * prm->multisample; s->prog_busy = 1;
     }
-    struct Done { rgk_scene* s; ~Done() { *(volatile uint32_t*)s->h_stage = s->prog_stages.load(); s->prog_busy = 0; } } done_guard{s};
-    uint32_t stage_target = 0; // what the stage word must read once everything queued so far has run
-    auto stage_mark = [&](uint32_t upto) -> int { // queued: "stages up to `upto` are done" (monotonic: bounces that never ran count too)
-        rgk_launch_stage_mark(st, s->h_stage, upto);
+    struct Done { rgk_scene* s; ~Done() { ((volatile uint32_t*)s->h_stage)[0] = s->prog_stages.load(); ((volatile uint32_t*)s->h_stage)[1] = 0; s->prog_busy = 0; } } done_guard{s};
+    uint32_t stage_targets[2] = {0, 0}; // per lane: what its stage word must read once everything queued on it so far has run
+    int lane = 0;
+    auto stage_mark = [&](uint32_t upto) -> int { // queued: "this lane's stages up to `upto` are done" (monotonic: bounces that never ran count too)
+        rgk_launch_stage_mark(st, s->h_stage + lane, upto);
         return 0;
     };
     PassParams pp{};
@@ -1496,7 +1520,7 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
     }
     if ((rc = s->htab.alloc((size_t)192 * prm->multisample))) return rc;
     TIMED(RGK_K_OTHER, rgk_launch_build_halton_table(st, s->dev, prm->multisample, s->htab.p));
-    pp.htab = s->htab.p; pp.light = s->light.p; pp.generic = s->generic.p;
+    pp.htab = s->htab.p;
     // Deep path loops (depth > 12): the length of the next queue is read back every other bounce from the fourth on; it
     // bounds the grids of the following launches (queues only shrink) and ends the loop once no path is left.
     auto queue_len = [&](const uint32_t* dptr, uint32_t& out) -> int {
@@ -1519,7 +1543,36 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
         out = h[0];
         return 0;
     };
-    const bool track = prm->depth > 12; // measured: depth 10 loses 4 % to the read-backs, depth 40 gains 4 %
+    // a lane's finished pass: wait for its stream, add its queue counters to the round's totals
+    bool pending[2] = {false, false};
+    uint32_t pend_n0[2] = {0, 0};
+    uint32_t pass_index = 0;
+    const bool light_entry_units = light_entry;
+    auto harvest = [&](int l) -> int {
+        HIPCHK(hipStreamSynchronize(l ? s->stream2 : s->stream));
+        pending[l] = false;
+        const uint32_t* hc = s->h_counters + (size_t)l * 2 * RGK_CNT_TOTAL;
+        const uint32_t n0 = pend_n0[l];
+        for (uint32_t b = 0; b < prm->depth; b++) { path_rays += hc[RGK_CNT_QUEUE + b]; shadow_rays += hc[RGK_CNT_SHADOW + b] + hc[RGK_CNT_SRAYS + b]; }
+        // what each kernel processed in this pass: rays / vertices, from the queue counters
+        units[RGK_K_TRACE_CAMERA] += hc[RGK_CNT_QUEUE]; units[RGK_K_SHADE_FIRST] += hc[RGK_CNT_QUEUE];
+        for (uint32_t b = 1; b < prm->depth; b++) { units[RGK_K_TRACE_CLOSEST] += hc[RGK_CNT_QUEUE + b]; units[RGK_K_SHADE] += hc[RGK_CNT_QUEUE + b]; }
+        for (uint32_t b = 0; b < prm->depth; b++) {
+            units[(b == 0 && light_entry_units) ? RGK_K_SHADOW_FIRST : RGK_K_SHADOW] += hc[RGK_CNT_SHADOW + b];
+            units[RGK_K_SHADOW_JOBS] += hc[RGK_CNT_CONN + b]; units[RGK_K_CONNECT] += hc[RGK_CNT_CONN + b];
+        }
+        for (uint32_t k = 0; k < R; k++) {
+            units[RGK_K_LIGHT_TRACE] += hc[RGK_CNT_TOTAL + RGK_CNT_QUEUE + k]; units[RGK_K_LIGHT_SHADE] += hc[RGK_CNT_TOTAL + RGK_CNT_HITS + k];
+            units[RGK_K_LIGHT_SPLAT] += hc[RGK_CNT_TOTAL + RGK_CNT_SHADOW + k];
+        }
+        units[RGK_K_RESOLVE] += n0;
+        // (light rays: the reference traces and counts one per path, path_tracer.cpp:126,349 -- the ones culled before the queue included)
+        for (uint32_t k = 0; k < R; k++) { path_rays += k == 0 ? n0 : hc[RGK_CNT_TOTAL + RGK_CNT_QUEUE + k]; shadow_rays += hc[RGK_CNT_TOTAL + RGK_CNT_SHADOW + k]; }
+        return 0;
+    };
+    // everything queued so far (pixel and seed lists, entry nodes, the Halton table) is on the first stream: the second waits for it
+    HIPCHK(hipEventRecord(s->ev_prelude, s->stream));
+    if (two) HIPCHK(hipStreamWaitEvent(s->stream2, s->ev_prelude, 0));
     for (size_t j0 = 0; j0 < P; j0 += npix_pass) {
         pp.j0 = (uint32_t)j0;
         pp.npix = (uint32_t)std::min(npix_pass, P - j0);
@@ -1532,21 +1585,37 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
                 pp.gshift = g;
             }
             const uint32_t n0 = pp.npix * pp.ns;
-            uint32_t* cn = s->counters.p;                   // camera-phase counters
-            uint32_t* cl = s->counters.p + RGK_CNT_TOTAL;   // light-phase counters
+            // which lane: its stream, its half of every workspace array, its counter blocks; a lane's previous pass is harvested
+            // (waited for, its counters added up) before the next one is queued on it
+            lane = two ? (int)(pass_index & 1u) : 0;
+            pass_index++;
+            st = lane ? s->stream2 : s->stream;
+            if (pending[lane] && (rc = harvest(lane))) return rc;
+            const size_t off = (size_t)lane * lane_cap;
+            float4* const w_rayA[2] = {s->rayA[0].p + off, s->rayA[1].p + off};
+            float4* const w_rayB[2] = {s->rayB[0].p + off, s->rayB[1].p + off};
+            float4 *const w_hit = s->hit.p + off, *const w_thr = s->thr.p + off, *const w_tot = s->tot.p + off;
+            float4 *const w_shA = s->shA.p + off, *const w_shB = s->shB.p + off, *const w_shC = s->shC.p + off;
+            pp.light = s->light.p + off; pp.generic = s->generic.p + off;
+            uint32_t* cn = s->counters.p + (size_t)lane * 2 * RGK_CNT_TOTAL; // camera-phase counters
+            uint32_t* cl = cn + RGK_CNT_TOTAL;                               // light-phase counters
+            uint32_t& stage_target = stage_targets[lane];
+            pend_n0[lane] = n0;
+            RgkTraceCfg tcl = s->tcfg; // (the lane's own overflow area of the traversal stack)
+            if (tcl.ovf) tcl.ovf += (size_t)lane * s->ovf_lane;
             if (R > 0) {
                 // light sub-path first (its sampler dimensions are fixed), splats straight into the accumulator
                 rgk_launch_set_bound(n0, n0);
                 TIMED(RGK_K_OTHER, rgk_launch_init_counters(st, cl, 0u)); // (k_raygen_light queues the light rays that can touch the scene's box)
-                TIMED(RGK_K_LIGHT_SHADE, rgk_launch_raygen_light(st, s->dev, cam, pp, s->rayA[0].p, s->rayB[0].p, s->thr.p, cl));
+                TIMED(RGK_K_LIGHT_SHADE, rgk_launch_raygen_light(st, s->dev, cam, pp, w_rayA[0], w_rayB[0], w_thr, cl));
                 for (uint32_t k = 0; k < R; k++) {
                     int q = k & 1;
-                    TIMED(RGK_K_LIGHT_TRACE, rgk_launch_trace_closest(st, s->dev, s->tcfg, count_stats, s->rayA[q].p, s->rayB[q].p, nullptr, s->hit.p,
+                    TIMED(RGK_K_LIGHT_TRACE, rgk_launch_trace_closest(st, s->dev, tcl, count_stats, w_rayA[q], w_rayB[q], nullptr, w_hit,
                                                       cl + RGK_CNT_QUEUE + k, cl + RGK_CNT_FETCH_T + k, s->stats.p));
-                    TIMED(RGK_K_LIGHT_SHADE, rgk_launch_list_hits(st, s->hit.p, cl + RGK_CNT_QUEUE + k, s->hitlist.p, cl + RGK_CNT_HITS + k));
-                    TIMED(RGK_K_LIGHT_SHADE, rgk_launch_shade_light(st, s->dev, cam, pp, k, s->rayA[q].p, s->rayB[q].p, s->hit.p, s->thr.p,
-                                                    s->rayA[q ^ 1].p, s->rayB[q ^ 1].p, s->shA.p, s->shB.p, s->shC.p, cl));
-                    TIMED(RGK_K_LIGHT_SPLAT, rgk_launch_trace_shadow(st, s->dev, s->tcfg, count_stats, s->shA.p, s->shB.p, s->shC.p, nullptr, nullptr,
+                    TIMED(RGK_K_LIGHT_SHADE, rgk_launch_list_hits(st, w_hit, cl + RGK_CNT_QUEUE + k, s->hitlist.p, cl + RGK_CNT_HITS + k));
+                    TIMED(RGK_K_LIGHT_SHADE, rgk_launch_shade_light(st, s->dev, cam, pp, k, w_rayA[q], w_rayB[q], w_hit, w_thr,
+                                                    w_rayA[q ^ 1], w_rayB[q ^ 1], w_shA, w_shB, w_shC, cl));
+                    TIMED(RGK_K_LIGHT_SPLAT, rgk_launch_trace_shadow(st, s->dev, tcl, count_stats, w_shA, w_shB, w_shC, nullptr, nullptr,
                                                      RGK_SHADOW_SPLAT, d_accum_rgb, cl + RGK_CNT_SHADOW + k, cl + RGK_CNT_FETCH_S + k, s->stats.p));
                 }
             }
@@ -1558,16 +1627,16 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
                     int q = b & 1;
                     rgk_launch_set_bound(ub, ub);
                     if (b == 0) // no ray queue at bounce 0: the camera ray of slot i is made where it is traced and shaded
-                        TIMED(RGK_K_TRACE_CAMERA, rgk_launch_trace_camera(st, s->dev, cam, pp, s->tcfg, count_stats, s->hit.p, cn + RGK_CNT_QUEUE, cn + RGK_CNT_FETCH_T, s->stats.p));
+                        TIMED(RGK_K_TRACE_CAMERA, rgk_launch_trace_camera(st, s->dev, cam, pp, tcl, count_stats, w_hit, cn + RGK_CNT_QUEUE, cn + RGK_CNT_FETCH_T, s->stats.p));
                     else
-                        TIMED(RGK_K_TRACE_CLOSEST, rgk_launch_trace_closest(st, s->dev, s->tcfg, count_stats, s->rayA[q].p, s->rayB[q].p, nullptr, s->hit.p,
+                        TIMED(RGK_K_TRACE_CLOSEST, rgk_launch_trace_closest(st, s->dev, tcl, count_stats, w_rayA[q], w_rayB[q], nullptr, w_hit,
                                                           cn + RGK_CNT_QUEUE + b, cn + RGK_CNT_FETCH_T + b, s->stats.p));
                     if (b == 0 && (cap_entries || light_entry)) {
                         // once per frame and pixel range (later rounds and sample ranges reuse it): how far the first hits of each
                         // pixel group lie -> camera-ray entry lists capped behind them, and where the group's shadow rays can go
                         const bool need_cap = cap_entries && (size_t)pp.j0 + pp.npix > s->entry_capped;
                         const bool need_light = light_entry && (size_t)pp.j0 + pp.npix > s->lentry_done;
-                        if (need_cap || need_light) TIMED(RGK_K_OTHER, rgk_launch_group_trange(st, pp, s->hit.p, s->trange.p));
+                        if (need_cap || need_light) TIMED(RGK_K_OTHER, rgk_launch_group_trange(st, pp, w_hit, s->trange.p));
                         if (need_cap) {
                             const uint32_t g_first = pp.j0 >> RGK_ENTRY_SHIFT, g_last = (uint32_t)(((size_t)pp.j0 + pp.npix + RGK_ENTRY_PIX - 1) >> RGK_ENTRY_SHIFT);
                             TIMED(RGK_K_OTHER, rgk_launch_entry_points(st, s->dev, cam, prm->xres, prm->yres, s->pix_xy.p, (uint32_t)P, g_first, g_last - g_first, s->trange.p, s->entry.p, s->entry_cap.p));
@@ -1590,46 +1659,31 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
                             }
                         }
                     }
-                    TIMED(b == 0 ? RGK_K_SHADE_FIRST : RGK_K_SHADE, rgk_launch_shade(st, s->dev, cam, pp, b, s->rayA[q].p, s->rayB[q].p, s->hit.p, s->thr.p, s->tot.p,
-                                              s->rayA[q ^ 1].p, s->rayB[q ^ 1].p, s->shA.p, s->shB.p, s->shC.p, cn, R > 0));
+                    TIMED(b == 0 ? RGK_K_SHADE_FIRST : RGK_K_SHADE, rgk_launch_shade(st, s->dev, cam, pp, b, w_rayA[q], w_rayB[q], w_hit, w_thr, w_tot,
+                                              w_rayA[q ^ 1], w_rayB[q ^ 1], w_shA, w_shB, w_shC, cn, R > 0));
                     if (R > 0) TIMED(RGK_K_CONNECT, rgk_launch_connect(st, s->dev, pp, b, s->jobs.p, s->rads.p, cn));
                     if (b == 0 && light_entry)
-                        TIMED(RGK_K_SHADOW_FIRST, rgk_launch_trace_shadow_first(st, s->dev, pp, s->tcfg, count_stats, s->shA.p, s->shB.p, s->shC.p, s->tot.p,
+                        TIMED(RGK_K_SHADOW_FIRST, rgk_launch_trace_shadow_first(st, s->dev, pp, tcl, count_stats, w_shA, w_shB, w_shC, w_tot,
                                                                cn + RGK_CNT_SHADOW + b, cn + RGK_CNT_FETCH_S + b, s->stats.p));
                     else
-                        TIMED(RGK_K_SHADOW, rgk_launch_trace_shadow(st, s->dev, s->tcfg, count_stats, s->shA.p, s->shB.p, s->shC.p, s->tot.p, nullptr,
+                        TIMED(RGK_K_SHADOW, rgk_launch_trace_shadow(st, s->dev, tcl, count_stats, w_shA, w_shB, w_shC, w_tot, nullptr,
                                                          RGK_SHADOW_ADD, nullptr, cn + RGK_CNT_SHADOW + b, cn + RGK_CNT_FETCH_S + b, s->stats.p));
                     if (R > 0) // (after the plain rays: both add into the slot sums, a slot has a vertex in ONE of the two queues)
-                        TIMED(RGK_K_SHADOW_JOBS, rgk_launch_trace_shadow_jobs(st, s->dev, pp, s->tcfg, count_stats, s->jobs.p, s->rads.p, s->tot.p,
+                        TIMED(RGK_K_SHADOW_JOBS, rgk_launch_trace_shadow_jobs(st, s->dev, pp, tcl, count_stats, s->jobs.p, s->rads.p, w_tot,
                                                               cn + RGK_CNT_CONN + b, cn + RGK_CNT_FETCH_J + b, s->stats.p));
                     if ((rc = stage_mark(stage_target + b + 1))) return rc;
                     if (track && b >= 3 && (b & 1) && b + 1 < prm->depth && (rc = queue_len(cn + RGK_CNT_QUEUE + b + 1, ub))) return rc;
                 }
             }
-            TIMED(RGK_K_RESOLVE, rgk_launch_resolve(st, pp, s->tot.p, s->pixsum.p, d_accum_rgb, d_accum_count));
+            TIMED(RGK_K_RESOLVE, rgk_launch_resolve(st, pp, w_tot, s->pixsum.p, d_accum_rgb, d_accum_count));
             stage_target += std::max(1u, prm->depth);
             if ((rc = stage_mark(stage_target))) return rc;
-            HIPCHK(hipMemcpyAsync(s->h_counters, s->counters.p, 2 * RGK_CNT_TOTAL * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            for (uint32_t b = 0; b < prm->depth; b++) { path_rays += s->h_counters[RGK_CNT_QUEUE + b]; shadow_rays += s->h_counters[RGK_CNT_SHADOW + b] + s->h_counters[RGK_CNT_SRAYS + b]; }
-            {   // what each kernel processed in this pass: rays / vertices, from the queue counters
-                const uint32_t* hc = s->h_counters;
-                units[RGK_K_TRACE_CAMERA] += hc[RGK_CNT_QUEUE]; units[RGK_K_SHADE_FIRST] += hc[RGK_CNT_QUEUE];
-                for (uint32_t b = 1; b < prm->depth; b++) { units[RGK_K_TRACE_CLOSEST] += hc[RGK_CNT_QUEUE + b]; units[RGK_K_SHADE] += hc[RGK_CNT_QUEUE + b]; }
-                for (uint32_t b = 0; b < prm->depth; b++) {
-                    units[(b == 0 && light_entry) ? RGK_K_SHADOW_FIRST : RGK_K_SHADOW] += hc[RGK_CNT_SHADOW + b];
-                    units[RGK_K_SHADOW_JOBS] += hc[RGK_CNT_CONN + b]; units[RGK_K_CONNECT] += hc[RGK_CNT_CONN + b];
-                }
-                for (uint32_t k = 0; k < R; k++) {
-                    units[RGK_K_LIGHT_TRACE] += hc[RGK_CNT_TOTAL + RGK_CNT_QUEUE + k]; units[RGK_K_LIGHT_SHADE] += hc[RGK_CNT_TOTAL + RGK_CNT_HITS + k];
-                    units[RGK_K_LIGHT_SPLAT] += hc[RGK_CNT_TOTAL + RGK_CNT_SHADOW + k];
-                }
-                units[RGK_K_RESOLVE] += n0;
-            }
-            // (light rays: the reference traces and counts one per path, path_tracer.cpp:126,349 -- the ones culled before the queue included)
-            for (uint32_t k = 0; k < R; k++) { path_rays += k == 0 ? n0 : s->h_counters[RGK_CNT_TOTAL + RGK_CNT_QUEUE + k]; shadow_rays += s->h_counters[RGK_CNT_TOTAL + RGK_CNT_SHADOW + k]; }
+            HIPCHK(hipMemcpyAsync(s->h_counters + (size_t)lane * 2 * RGK_CNT_TOTAL, cn, 2 * RGK_CNT_TOTAL * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            pending[lane] = true;
+            if (!two && (rc = harvest(lane))) return rc;
         }
     }
+    for (int l = 0; l < 2; l++) if (pending[l] && (rc = harvest(l))) return rc;
     HIPCHK(hipGetLastError());
     s->prog_rounds++;
     if (counters) {

@@ -575,6 +575,11 @@ def test_round_properties_cornell_config2_size(rd, oracle):
     a4, c4, _ = g.render_round(wl.camera, prm, tiles)
     g.set_tuning(batch_paths=0)
     assert np.array_equal(acc, a4)
+    # the two halves of the pixel list side by side on two streams (an experiment that did not pay; kept switchable): the same bits
+    g.set_tuning(two_lanes=1)
+    a6, c6, k6 = g.render_round(wl.camera, prm, tiles)
+    g.set_tuning(two_lanes=0)
+    assert np.array_equal(acc, a6) and np.array_equal(cnt, c6) and (k6.path_rays, k6.shadow_rays) == (k.path_rays, k.shadow_rays)
     # linearity of the accumulator: a second round adds
     tiles_b = rd.generate_task_list(wl.xres, wl.yres, seedcount_base=len(tiles))
     a5 = acc.copy(); c5 = cnt.copy()
