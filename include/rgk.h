@@ -294,7 +294,7 @@ int rgk_scene_get_progress(const rgk_scene *scene, rgk_progress *out);
 /* Tuning switches of ONE scene; none of them changes a result (the tests render with each and compare bits).  Keys:
  * "entry_points", "entry_cap", "light_entry" (0 / 1: where camera rays and first shadow rays start their walk), "sample_group"
  * (log2 of the samples of a pixel that sit side by side in the path-slot order, 0..6; -1: default), "batch_paths" (paths per
- * pass; 0: sized from the free memory), "workspace_gb" (0: default), "two_lanes" (0 / 1: an experiment, off).  Their initial values are read from the environment
+ * pass; 0: sized from the free memory), "workspace_gb" (0: default), "beam" (0 / 1: camera rays of a pixel walk the tree together), "two_lanes" (0 / 1: an experiment, off).  Their initial values are read from the environment
  * (RGK_ENTRY_POINTS, RGK_ENTRY_CAP, RGK_LIGHT_ENTRY, RGK_SAMPLE_GROUP, RGK_BATCH_PATHS, RGK_WORKSPACE_GB) ONCE, in
  * rgk_scene_create; a round never reads the environment.  Not while a round is in flight on this scene. */
 int rgk_scene_set_tuning(rgk_scene *scene, const char *key, double value);

@@ -47,6 +47,7 @@
 struct PassParams {
     uint32_t j0, npix, s0, ns;
     uint32_t gshift;
+    uint32_t beam;            // bounce 0 of a pinhole camera with gshift == 3: one lane walks the tree for the 8 samples of a pixel (k_trace_camera_beam)
     uint32_t multisample, depth, xres, yres;
     float clamp, russian, bumpmap_scale;
     uint32_t reverse;

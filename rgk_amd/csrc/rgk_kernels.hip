@@ -809,6 +809,14 @@ void rgk_launch_build_halton_table(hipStream_t st, const DevScene& sc, uint32_t 
 // bounce 0 of a unidirectional pass: camera rays generated in the traversal kernel (no queue)
 void rgk_launch_trace_camera(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, const RgkTraceCfg& tc, bool count_stats, float4* hit,
                              const uint32_t* count_ptr, uint32_t* fetch, unsigned long long* stats) {
+    if (pp.beam && pp.gshift == 3 && cam.lens_size == 0.0f && tc.lds < tc.stack) {
+        // 8 stack entries per lane in LDS (the rest in the overflow area): with the bundle's 32 floats per lane that makes 40 KB per
+        // workgroup, four workgroups per CU
+        const int grid = bounded_grid(rgk_trace_grid(tc.lds), (g_bound >> 3) + 1u, RGK_TRACE_BLOCK);
+        if (count_stats) k_trace_camera_beam<true, 256, 8><<<grid, RGK_TRACE_BLOCK, 0, st>>>(sc, cam, pp, hit, count_ptr, fetch, stats, tc.ovf);
+        else k_trace_camera_beam<false, 256, 8><<<grid, RGK_TRACE_BLOCK, 0, st>>>(sc, cam, pp, hit, count_ptr, fetch, stats, tc.ovf);
+        return;
+    }
     RGK_TRACE_DISPATCH(k_trace_camera, g_bound, sc, cam, pp, hit, count_ptr, fetch, stats, tc.ovf)
 }
 

@@ -528,6 +528,235 @@ __global__ __launch_bounds__(RGK_TRACE_BLOCK, (LDSN <= 16 ? RGK_TRACE_WAVES : 5)
     }
 }
 
+// ------------------------------------------------------------------ K1 + K2 at bounce 0, one lane per PIXEL: the beam walk
+// The 8 samples of a pixel that sit side by side in the slot order (PassParams::gshift = 3) are rays from ONE origin (a pinhole
+// camera) through one pixel: they walk the same nodes.  Here one lane walks the tree ONCE for the eight of them -- a node is
+// entered when the bundle can enter it: per axis the rays' reciprocal directions as an interval, the slab distances as interval
+// products (conservative: widened by a few ulps, boxes are epsilon-padded on top) -- and at a leaf every triangle is tested
+// against each of the 8 rays with the same tri_test, the same acceptance window (its own clip to the scene box) and the same tie
+// rule as k_trace_camera.  A ray's result is the nearest accepted hit among the triangles of every leaf ITS OWN walk would have
+// reached (the bundle reaches a superset, and a hit beyond the ray's own pruning distance loses to the nearer one anyway): the
+// same hit, bit for bit.  Node work per ray drops eight-fold; the 64 lanes of a wave are an 8 x 8 pixel block.
+// Capped entry lists (k_entry_points): rays that find nothing within the group's cap are walked again, together, from the root.
+#ifndef RGK_BEAM_WAVES
+#define RGK_BEAM_WAVES 4
+#endif
+template <bool COUNT, int STACK, int LDSN>
+__global__ __launch_bounds__(RGK_TRACE_BLOCK, RGK_BEAM_WAVES) void k_trace_camera_beam(const DevScene sc, const DevCamera cam, const PassParams pp,
+                                                                    float4* hit, const uint32_t* __restrict__ count_ptr,
+                                                                    uint32_t* __restrict__ fetch, unsigned long long* __restrict__ stats, int* __restrict__ ovf_base) {
+    __shared__ int lds_stack[LDSN * RGK_TRACE_BLOCK];
+    __shared__ float lds_ray[32 * RGK_TRACE_BLOCK]; // per lane, [entry][lane]: the 8 directions (24 floats) and the 8 nearest accepted distances
+    int* __restrict__ stack = lds_stack + threadIdx.x;
+    float* __restrict__ ray = lds_ray + threadIdx.x;
+#define RGK_D(k_) mk3(ray[(3 * (k_) + 0) * RGK_TRACE_BLOCK], ray[(3 * (k_) + 1) * RGK_TRACE_BLOCK], ray[(3 * (k_) + 2) * RGK_TRACE_BLOCK])
+#define RGK_BEST(k_) ray[(24 + (k_)) * RGK_TRACE_BLOCK]
+    int* __restrict__ ovf = ovf_base + (blockIdx.x * RGK_TRACE_BLOCK + threadIdx.x);
+    const uint32_t ostride = gridDim.x * RGK_TRACE_BLOCK;
+    const int stride = RGK_TRACE_BLOCK;
+    const int lane = threadIdx.x & 63;
+    const float eps = sc.epsilon;
+    const int walk_q = (int)sc.walk_q;
+    const float4* __restrict__ nodes = reinterpret_cast<const float4*>(sc.nodes);
+    const float4* __restrict__ tris = reinterpret_cast<const float4*>(sc.tris);
+    const SamplerTab tb = {pp.htab, pp.multisample};
+    const uint32_t count = (*count_ptr) >> 3; // bundles: 8 slots each
+    const uint32_t chunk = fetch_chunk(count, gridDim.x * (RGK_TRACE_BLOCK / 64), 16u);
+    uint32_t w_next = 0, w_end = 0;
+    bool exhausted = false;
+    uint32_t n_nodes = 0, n_tris = 0;
+    // per-lane bundle state
+    bool active = false, capped = false;
+    uint32_t idx = 0, valid = 0; // valid: bit k = sample k still looks for its hit in this walk
+    f3 o = mk3(0.f, 0.f, 0.f), imin = o, imax = o;
+    // (a sample's whole hit record {t, alpha, beta, triangle} lives in hit[] from the start: written as "miss" when the bundle is
+    // set up, overwritten whenever a nearer hit is accepted; directions and nearest distances sit in LDS, indexed by the sample)
+    uint32_t axis_mode = 0; // 2 bits per axis: 0 all directions positive, 1 all negative, 2 mixed (the axis cannot exclude a box)
+    float bmax = 0.f, btlo = 0.f, capd = 0.f;
+    int cur = STACK_SENTINEL, sp = 0;
+
+    // the bundle's direction intervals and pruning bounds over the samples in `valid`
+#define RGK_BEAM_BOUNDS()                                                                                                              \
+    {                                                                                                                                  \
+        f3 dmin = mk3(__builtin_inff(), __builtin_inff(), __builtin_inff()), dmax = -dmin;                                             \
+        btlo = __builtin_inff();                                                                                                       \
+        for (int k = 0; k < 8; k++) if (valid & (1u << k)) {                                                                          \
+            const f3 dk_ = RGK_D(k);                                                                                                   \
+            dmin = mk3(fminf(dmin.x, dk_.x), fminf(dmin.y, dk_.y), fminf(dmin.z, dk_.z));                                              \
+            dmax = mk3(fmaxf(dmax.x, dk_.x), fmaxf(dmax.y, dk_.y), fmaxf(dmax.z, dk_.z));                                              \
+            float t0_, t1_; (void)clip_to_scene(sc, o, dk_, 0.0f, 10000.0f, t0_, t1_); btlo = fminf(btlo, t0_ - eps);                  \
+        }                                                                                                                              \
+        axis_mode = 0;                                                                                                                 \
+        float lo_[3] = {dmin.x, dmin.y, dmin.z}, hi_[3] = {dmax.x, dmax.y, dmax.z}, im_[3], ix_[3];                                    \
+        _Pragma("unroll") for (int a = 0; a < 3; a++) {                                                                                \
+            const uint32_t m = lo_[a] > 0.f ? 0u : (hi_[a] < 0.f ? 1u : 2u);                                                           \
+            axis_mode |= m << (2 * a);                                                                                                 \
+            float a0 = 1.f / hi_[a], a1 = 1.f / lo_[a]; /* 1/d over [lo, hi] of one sign: [1/hi, 1/lo] */                              \
+            a0 -= fabsf(a0) * 4e-7f; a1 += fabsf(a1) * 4e-7f;                                                                          \
+            im_[a] = m == 2u ? 0.f : fminf(fmaxf(a0, -1e30f), 1e30f); ix_[a] = m == 2u ? 0.f : fminf(fmaxf(a1, -1e30f), 1e30f);       \
+        }                                                                                                                              \
+        imin = mk3(im_[0], im_[1], im_[2]); imax = mk3(ix_[0], ix_[1], ix_[2]);                                                        \
+    }
+
+    for (;;) {
+        // ------------------------------------------------ refill idle lanes with fresh bundles
+        unsigned long long act = __ballot(active);
+        const int nact = __popcll(act);
+        if (nact <= RGK_REFILL_BELOW && !(exhausted && w_next >= w_end)) {
+            if (w_next >= w_end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(fetch, chunk);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= count) exhausted = true;
+                else { w_next = base; w_end = min(base + chunk, count); }
+            }
+            const uint32_t avail = (w_end > w_next) ? (w_end - w_next) : 0u;
+            if (avail) {
+                const uint32_t rank = __popcll(~act & ((1ull << lane) - 1ull));
+                if (!active && rank < avail) {
+                    idx = w_next + rank;
+                    const uint32_t sb = idx / pp.npix, j = idx - sb * pp.npix; // slot = idx << 3 | k  (slot_decode with gshift = 3)
+                    const uint32_t pix = pp.pix_xy[pp.j0 + j], seed = pp.pix_seed[pp.j0 + j];
+                    valid = 0;
+                    for (int k = 0; k < 8; k++) {
+                        const float2 jit = sample2d_t(tb, seed, pp.s0 + (sb << 3) + (uint32_t)k, 0);
+                        f3 dk;
+                        camera_ray(cam, (int)(pix & 0xffff), (int)(pix >> 16), (int)pp.xres, (int)pp.yres, jit, make_float2(0.f, 0.f), o, dk);
+                        ray[(3 * k + 0) * RGK_TRACE_BLOCK] = dk.x; ray[(3 * k + 1) * RGK_TRACE_BLOCK] = dk.y; ray[(3 * k + 2) * RGK_TRACE_BLOCK] = dk.z;
+                        RGK_BEST(k) = __builtin_inff();
+                        hit[((size_t)idx << 3) + k] = make_float4(__builtin_inff(), 0.f, 0.f, __int_as_float(-1));
+                        const bool nan_ray = (o.x != o.x) | (o.y != o.y) | (o.z != o.z) | (dk.x != dk.x) | (dk.y != dk.y) | (dk.z != dk.z);
+                        float t0, t1;
+                        if (!nan_ray && clip_to_scene(sc, o, dk, 0.0f, 10000.0f, t0, t1)) valid |= 1u << k;
+                    }
+                    sp = 0;
+                    cur = STACK_SENTINEL;
+                    capped = false;
+                    capd = __builtin_inff();
+                    bmax = __builtin_inff();
+                    if (valid) {
+                        RGK_BEAM_BOUNDS()
+                        cur = 0;
+                        if (pp.entry) {
+                            const size_t grp = (size_t)((pp.j0 + j) >> RGK_ENTRY_SHIFT);
+                            capd = pp.entry_cap[grp];
+                            capped = capd < __builtin_inff();
+                            const int* e = pp.entry + grp * RGK_ENTRY_K;
+                            cur = e[0];
+#pragma unroll
+                            for (int k = RGK_ENTRY_K - 1; k >= 1; k--) { const int r = e[k]; if (r != STACK_SENTINEL) { RGK_PUT(r) sp++; } }
+                        }
+                    }
+                    active = true;
+                }
+                w_next += min(avail, (uint32_t)(64 - nact));
+            }
+            act = __ballot(active);
+        }
+        if (act == 0) {
+            if (exhausted && w_next >= w_end) break;
+            continue;
+        }
+        // ------------------------------------------------ inner nodes (same scheduling as trace_persistent)
+        for (;;) {
+            const bool walking = (uint32_t)cur < (uint32_t)STACK_SENTINEL;
+            const int n_walk = __popcll(__builtin_amdgcn_ballot_w64(walking));
+            if (n_walk == 0) break;
+            if (n_walk * 4 < __popcll(__builtin_amdgcn_ballot_w64(cur < 0)) * walk_q) break;
+            if (!walking) continue;
+            if (COUNT) n_nodes++;
+            const float limit = fminf(bmax, capd);
+            const float4 n0 = nodes[4 * cur + 0], n1 = nodes[4 * cur + 1], n2 = nodes[4 * cur + 2], n3 = nodes[4 * cur + 3];
+            const float sx = n0.w, sy = n3.z, sz = n3.w;
+            const float px = n0.x - o.x, py = n0.y - o.y, pz = n0.z - o.z;
+            const uint32_t mx = axis_mode & 3u, my = (axis_mode >> 2) & 3u, mz = (axis_mode >> 4) & 3u;
+            const uint32_t lx = __float_as_uint(n2.x), ly = __float_as_uint(n2.y), lz = __float_as_uint(n2.z);
+            const uint32_t hx = __float_as_uint(n2.w), hy = __float_as_uint(n3.x), hz = __float_as_uint(n3.y);
+            const uint32_t nx = mx == 1u ? hx : lx, fx = mx == 1u ? lx : hx; // near / far plane words by the bundle's direction sign
+            const uint32_t ny = my == 1u ? hy : ly, fy = my == 1u ? ly : hy;
+            const uint32_t nz = mz == 1u ? hz : lz, fz = mz == 1u ? lz : hz;
+            float te[4];
+            int ref[4];
+            ref[0] = __float_as_int(n1.x); ref[1] = __float_as_int(n1.y); ref[2] = __float_as_int(n1.z); ref[3] = __float_as_int(n1.w);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                // plane - origin, then its distance over the bundle: the interval product (plane - o) * [imin, imax]
+                const float rnx = __builtin_fmaf(cvt_ubyte(nx, c), sx, px), rfx = __builtin_fmaf(cvt_ubyte(fx, c), sx, px);
+                const float rny = __builtin_fmaf(cvt_ubyte(ny, c), sy, py), rfy = __builtin_fmaf(cvt_ubyte(fy, c), sy, py);
+                const float rnz = __builtin_fmaf(cvt_ubyte(nz, c), sz, pz), rfz = __builtin_fmaf(cvt_ubyte(fz, c), sz, pz);
+                float t0x = fminf(rnx * imin.x, rnx * imax.x), t1x = fmaxf(rfx * imin.x, rfx * imax.x);
+                float t0y = fminf(rny * imin.y, rny * imax.y), t1y = fmaxf(rfy * imin.y, rfy * imax.y);
+                float t0z = fminf(rnz * imin.z, rnz * imax.z), t1z = fmaxf(rfz * imin.z, rfz * imax.z);
+                if (mx == 2u) { t0x = -__builtin_inff(); t1x = __builtin_inff(); }
+                if (my == 2u) { t0y = -__builtin_inff(); t1y = __builtin_inff(); }
+                if (mz == 2u) { t0z = -__builtin_inff(); t1z = __builtin_inff(); }
+                const float tn = fmaxf(fmaxf(fmaxf(t0x, t0y), t0z), btlo);
+                const float tf = fminf(fminf(fminf(t1x, t1y), t1z), limit);
+                const bool h = (ref[c] != STACK_SENTINEL) && (tn <= tf); // (an unused slot carries the sentinel as its child code)
+                te[c] = h ? tn : __builtin_inff();
+                if (!h) ref[c] = STACK_SENTINEL;
+            }
+#define RGK_CSWAP(a, b) { const bool sw = te[b] < te[a]; const float tt = sw ? te[b] : te[a], tu = sw ? te[a] : te[b]; \
+                          const int rr = sw ? ref[b] : ref[a], ru = sw ? ref[a] : ref[b]; te[a] = tt; te[b] = tu; ref[a] = rr; ref[b] = ru; }
+            RGK_CSWAP(0, 1) RGK_CSWAP(2, 3) RGK_CSWAP(0, 2) RGK_CSWAP(1, 3) RGK_CSWAP(1, 2)
+#undef RGK_CSWAP
+            RGK_PUT(ref[3]) sp += (ref[3] != STACK_SENTINEL);
+            RGK_PUT(ref[2]) sp += (ref[2] != STACK_SENTINEL);
+            RGK_PUT(ref[1]) sp += (ref[1] != STACK_SENTINEL);
+            cur = ref[0];
+            if (cur == STACK_SENTINEL && sp > 0) { sp--; cur = RGK_POP(); }
+        }
+        // ------------------------------------------------ leaf: every triangle of it against every sample of the bundle
+        if (active && cur < 0) {
+            const uint32_t code = ~(uint32_t)cur;
+            const uint32_t first = code >> 4, cnt = (code & 15u) + 1u;
+            for (uint32_t k = 0; k < cnt; k++) {
+                const float4 r0 = tris[3 * (first + k) + 0], r1 = tris[3 * (first + k) + 1], r2 = tris[3 * (first + k) + 2];
+                const int tid = (int)__float_as_uint(r2.w);
+                if (COUNT) n_tris += (uint32_t)__popc(valid);
+                for (int q = 0; q < 8; q++) {
+                    if (!(valid & (1u << q))) continue;
+                    const f3 dq = RGK_D(q);
+                    float t, al, be;
+                    if (!tri_test(r0, r1, r2, o, dq, eps, t, al, be)) continue;
+                    // the ray's own acceptance window: its [near, far] clipped to the scene box (and to the group's cap)
+                    float t0, t1;
+                    (void)clip_to_scene(sc, o, dq, 0.0f, 10000.0f, t0, t1);
+                    const float thi = capped ? fminf(t1 + eps, capd) : t1 + eps;
+                    if (t < t0 - eps || t > thi) continue;
+                    const float bq = RGK_BEST(q);
+                    bool take = t < bq;
+                    if (t == bq) take = tid > __float_as_int(hit[((size_t)idx << 3) + q].w); // an exact tie: the higher triangle id (its own earlier write, same lane)
+                    if (take) { RGK_BEST(q) = t; hit[((size_t)idx << 3) + q] = make_float4(t, al, be, __int_as_float(tid)); }
+                }
+            }
+            bmax = 0.f; // nothing beyond the farthest sample's nearest hit can matter to any of them
+            for (int q = 0; q < 8; q++) if (valid & (1u << q)) bmax = fmaxf(bmax, RGK_BEST(q));
+            if (sp > 0) { sp--; cur = RGK_POP(); }
+            else cur = STACK_SENTINEL;
+        }
+        // ------------------------------------------------ retire: walk again from the root for samples the capped list left empty-handed
+        if (active && cur == STACK_SENTINEL) {
+            uint32_t again = 0;
+            if (capped) {
+                for (int q = 0; q < 8; q++) if ((valid & (1u << q)) && RGK_BEST(q) == __builtin_inff()) again |= 1u << q;
+            }
+            if (again) {
+                valid = again; capped = false; capd = __builtin_inff(); bmax = __builtin_inff();
+                RGK_BEAM_BOUNDS()
+                cur = 0; sp = 0;
+            } else active = false; // (the records are in hit[] already)
+        }
+    }
+#undef RGK_BEAM_BOUNDS
+#undef RGK_D
+#undef RGK_BEST
+    if (COUNT) {
+        atomicAdd(&stats[0], (unsigned long long)n_nodes);
+        atomicAdd(&stats[1], (unsigned long long)n_tris);
+    }
+}
+
 // ------------------------------------------------------------------ K5: shadow rays + accumulate
 // shA = (o.xyz, d.x)  shB = (d.y, d.z, far, slot)  shC = (radiance.rgb, near)
 template <bool COUNT, int STACK, int LDSN>

@@ -267,8 +267,9 @@ def test_entry_nodes_do_not_change_the_image(rd):
         g = rd.Scene(wl.builder.to_desc())
         tiles = rd.generate_task_list(wl.xres, wl.yres)
         imgs = []
-        for cam_entry, cap, light_entry in ((0, 0, 0), (1, 0, 0), (1, 1, 0), (1, 1, 1)):
-            gg = rd.Scene(wl.builder.to_desc()).set_tuning(entry_points=cam_entry, entry_cap=cap, light_entry=light_entry)  # (a fresh scene per variant: nothing cached from the previous one)
+        # ... and the walker of a frame's first round: one lane per pixel for its 8 samples (k_trace_camera_beam, beam = 1) or one lane per ray
+        for cam_entry, cap, light_entry, beam in ((0, 0, 0, 0), (0, 0, 0, 1), (1, 0, 0, 1), (1, 0, 0, 0), (1, 1, 0, 1), (1, 1, 1, 1), (1, 1, 1, 0)):
+            gg = rd.Scene(wl.builder.to_desc()).set_tuning(entry_points=cam_entry, entry_cap=cap, light_entry=light_entry, beam=beam)  # (a fresh scene per variant: nothing cached from the previous one)
             acc, cnt, k = gg.render_round(wl.camera, wl.params(), tiles)
             acc2, _, k2 = gg.render_round(wl.camera, wl.params(), tiles)   # second round of the frame: lists capped behind the first hits
             assert np.array_equal(acc, acc2) and k.path_rays == k2.path_rays and k.shadow_rays == k2.shadow_rays, (name, kw, cam_entry, cap, light_entry)
