@@ -492,7 +492,8 @@ struct RgkTuning {
     int sample_group = -1;    // log2 of the samples of a pixel side by side in the slot order; -1: the compiled default
     size_t batch_paths = 0;   // paths per pass; 0: sized from the memory that is free
     double workspace_gb = 0;  // ... or from this many GB; 0: 96 (160 for bidirectional rounds), at most 60 % of what is free
-    bool beam = true;         // pinhole cameras, a frame's first round: bounce 0 walks the tree once per pixel for 8 samples (k_trace_camera_beam)
+    int beam = 1;             // pinhole cameras: bounce 0 walks the tree once per pixel for 8 samples (k_trace_camera_beam) -- 1: while the
+                              // entry lists are uncapped (a frame's first round), 2: always, 0: never
     bool two_lanes = false;   // experiment (measured: no gain, see render_round): the two halves of the pixel list as two passes on two streams
     bool debug_bvh = false, debug_util = false;
 };
@@ -847,7 +848,7 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
         if (const char* e = std::getenv("RGK_SAMPLE_GROUP")) t.sample_group = std::min(6, std::max(0, std::atoi(e)));
         if (const char* e = std::getenv("RGK_BATCH_PATHS")) t.batch_paths = std::max<size_t>(1024, strtoull(e, nullptr, 10));
         if (const char* e = std::getenv("RGK_WORKSPACE_GB")) t.workspace_gb = atof(e);
-        t.beam = !off("RGK_BEAM");
+        if (const char* e = std::getenv("RGK_BEAM")) t.beam = std::min(2, std::max(0, std::atoi(e)));
         { const char* e = std::getenv("RGK_TWO_LANES"); t.two_lanes = e && e[0] == '1'; }
         t.debug_bvh = std::getenv("RGK_DEBUG_BVH") != nullptr; t.debug_util = std::getenv("RGK_DEBUG_UTIL") != nullptr;
     }
@@ -1292,7 +1293,7 @@ int rgk_scene_set_tuning(rgk_scene* s, const char* key, double value) {
     else if (k == "batch_paths") t.batch_paths = value <= 0 ? 0 : std::max<size_t>(1024, (size_t)value);
     else if (k == "workspace_gb") t.workspace_gb = value <= 0 ? 0.0 : value;
     else if (k == "two_lanes") t.two_lanes = value != 0;
-    else if (k == "beam") t.beam = value != 0;
+    else if (k == "beam") t.beam = (int)std::min(2.0, std::max(0.0, value));
     else return fail(RGK_ERR_INVALID, "unknown tuning key '%s'", key);
     // per-frame lists were made under the old switches: the next round rebuilds them
     s->entry_key = 0; s->entry_n = 0; s->entry_capped = 0; s->lentry_done = 0;
@@ -1591,7 +1592,7 @@ int rgk_render_round_device(rgk_scene* s, const rgk_camera* camera, const rgk_pa
                 // frame 135.2 -> 130.8 ms; against CAPPED lists the per-ray walk is the faster one (16.1 vs 17.2: a bundle tests
                 // every triangle it meets against all 8 rays, 2.86 tests per ray instead of 2.57, at half the occupancy)
                 const bool lists_capped = cap_entries && (size_t)pp.j0 + pp.npix <= s->entry_capped;
-                pp.beam = (s->tune.beam && !lists_capped) ? 1u : 0u;
+                pp.beam = (s->tune.beam == 2 || (s->tune.beam == 1 && !lists_capped)) ? 1u : 0u;
             }
             const uint32_t n0 = pp.npix * pp.ns;
             // which lane: its stream, its half of every workspace array, its counter blocks; a lane's previous pass is harvested

@@ -73,6 +73,10 @@ __device__ __forceinline__ void camera_ray_of_slot(const DevCamera& cam, const P
 // Triangle::TestIntersection, reference src/primitives.cpp:75-166.  r0..r2 = TriIsect.
 __device__ __forceinline__ bool tri_test(const float4 r0, const float4 r1, const float4 r2, const f3 o, const f3 d,
                                          const float eps, float& t, float& alpha, float& beta) {
+#if defined(RGK_DIAG_NO_TRI) /* timing diagnosis only (wrong images): what the walkers cost without their triangle tests */
+    t = r0.x + r1.x + r2.x + o.x + d.x; alpha = beta = 0.f;
+    return t == 12345.678f;
+#endif
     f3 n = mk3(r0.x, r0.y, r0.z);
     double dotv = (double)dot3(d, n);
     if (dotv != dotv) return false;
@@ -100,6 +104,15 @@ __device__ __forceinline__ bool tri_test(const float4 r0, const float4 r1, const
     return true;
 }
 
+// (A conservative fp32 look at a (ray, triangle) pair BEFORE this test -- plane distance through the hardware reciprocal, the hit
+// point's three edge functions without any division, every comparison with a margin far above the rounding that separates it
+// from the exact test, NaN-safe -- was built and measured in round 3: every parity test stayed bit-identical, and it lost
+// everywhere.  In the per-ray walkers its ~20 extra live registers turn the 64-VGPR / 8-wave kernels' 12-44 bytes of scratch
+// into 100-160: Sponza 1080p x 256, ms per round 126.8 -> 195.0 at 8 waves per SIMD, 153.8 at 7, 143.3 at 6.  In the bundle
+// walker, which has registers to spare, the camera launch went 17.4 -> 18.8 ms: the exact test's own early outs are about as
+// cheap as the look that would avoid it.  Running every test TWICE costs the camera launch +6.2 ms of 16.1, the bounce launch
+// +8.8 of 36.2, the shadow launches +2.4 of 16.9 -- triangle tests are 14 % of a round; the node loads and box tests, doubled the
+// same way, +4.7, +17.1 and +6.2.)
 // Scene-bbox clip of [near, far], reference src/scene_intersect.cpp:223-232
 __device__ __forceinline__ bool clip_to_scene(const DevScene& sc, f3 o, f3 d, float tnear, float tfar, float& t0, float& t1) {
     t0 = tnear; t1 = tfar;
@@ -361,6 +374,9 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
             float te[4];
             int ref[4];
             if (COUNT) n_nodes++;
+#if defined(RGK_DIAG_NODE_TWICE) /* timing diagnosis only: the node's loads and box tests twice */
+            for (int rep_ = 0; rep_ < 2; rep_++) { asm volatile("" : "+v"(cur));
+#endif
             const float limit = ANY ? thi : fminf(thi, best_t);
             // one 64-byte QNode: {p.xyz, sx} {child[4]} {qlo.x qlo.y qlo.z qhi.x} {qhi.y qhi.z sy sz}
             // (the SGPR-base + 32-bit-offset load form of rgk_device.h gld_* was measured here: 23.8 vs 23.0 ms, not kept)
@@ -394,6 +410,9 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
                 te[c] = h ? tn : __builtin_inff();
                 if (!h) ref[c] = STACK_SENTINEL;
             }
+#if defined(RGK_DIAG_NODE_TWICE)
+            asm volatile("" :: "v"(te[0]), "v"(te[1]), "v"(te[2]), "v"(te[3]), "v"(ref[0]), "v"(ref[1]), "v"(ref[2]), "v"(ref[3])); }
+#endif
             if (!ANY) {
                 // sort the four (entry distance, ref) pairs ascending: 5-comparator network
 #define RGK_CSWAP(a, b) { const bool sw = te[b] < te[a]; const float tt = sw ? te[b] : te[a], tu = sw ? te[a] : te[b]; \
@@ -444,7 +463,11 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
                 if (tid == ignore) continue;
                 if (COUNT) n_tris++;
                 float t, al, be;
-                if (tri_test(r0, r1, r2, o, d, eps, t, al, be)) {
+                bool hit_ = tri_test(r0, r1, r2, o, d, eps, t, al, be);
+#if defined(RGK_DIAG_TRI_TWICE) /* timing diagnosis only: the same test a second time (the optimiser cannot see that it is the same) */
+                { f3 o2 = o; asm volatile("" : "+v"(o2.x)); float t2, a2, b2; const bool h2 = tri_test(r0, r1, r2, o2, d, eps, t2, a2, b2); if (h2 != hit_) { t = t2; hit_ = h2; } }
+#endif
+                if (hit_) {
                     if (t < tlo || t > thi) continue;
                     // Exact ties go to the HIGHER triangle id, so that the result does not depend on the order in which this walker
                     // happens to reach the leaves (it changes with every change to the tree builder).  The reference takes the first
