@@ -34,6 +34,9 @@
 #ifndef RGK_JOB_FINISH_ATOMIC
 #define RGK_JOB_FINISH_ATOMIC 0 // the vertex total into the slot sum as three float atomics instead of a read-modify-write
 #endif
+#ifndef RGK_JOB_REFILL_BELOW
+#define RGK_JOB_REFILL_BELOW 24 // the vertex queue's walker: lanes between two rays of their vertex wait for the refill too
+#endif
 #ifndef RGK_REFILL_BELOW
 #define RGK_REFILL_BELOW 24 // refill a wave when at most this many lanes still hold a ray (swept 8..60 with the majority walk: 24 best)
 #endif
@@ -216,7 +219,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
         unsigned long long act = JOB ? __ballot(active && !seg_pending) : occ;
         const int nact = __popcll(act);
         if (COUNT) u_outer_it++;
-        const bool refill_now = nact <= RGK_REFILL_BELOW;
+        const bool refill_now = nact <= (JOB ? RGK_JOB_REFILL_BELOW : RGK_REFILL_BELOW);
         if (refill_now && !(exhausted && w_next >= w_end)) {
             if (COUNT) u_refill++;
             if (w_next >= w_end) {
