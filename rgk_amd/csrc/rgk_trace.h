@@ -177,7 +177,12 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
     const float4* __restrict__ nodes = reinterpret_cast<const float4*>(sc.nodes);
     const float4* __restrict__ tris = reinterpret_cast<const float4*>(sc.tris);
     const uint32_t chunk = fetch_chunk(count, gridDim.x * (RGK_TRACE_BLOCK / 64), ANY ? 4u : 16u);
-    uint32_t w_next = 0, w_end = 0; // wave-uniform: this wave's slice of the queue
+    // A wave's FIRST slice is dealt statically (wave w takes [w * chunk, (w + 1) * chunk)), the later ones through the device-wide
+    // cursor, which therefore counts from n_waves * chunk.  With the cursor alone every one of a launch's ~8000 waves started with
+    // a returning atomic on one word (~88 per microsecond chip-wide): ~90 us per launch whatever its work -- for the hundreds of
+    // short launches of a deep path loop, most of their time.  A wave whose static slice lies beyond the queue leaves at once.
+    const uint32_t n_waves = gridDim.x * (RGK_TRACE_BLOCK / 64), wave_id = blockIdx.x * (RGK_TRACE_BLOCK / 64) + (threadIdx.x >> 6);
+    uint32_t w_next = min(wave_id * chunk, count), w_end = min(w_next + chunk, count); // wave-uniform: this wave's slice of the queue
     bool exhausted = false;         // wave-uniform: the device cursor has passed `count`
     // per-lane ray state
     bool active = false;
@@ -224,7 +229,8 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
             if (COUNT) u_refill++;
             if (w_next >= w_end) {
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(fetch, chunk);
+                if (n_waves * chunk >= count) base = count; // (the static slices covered the queue: no cursor traffic at all)
+                else if (lane == 0) base = atomicAdd(fetch, chunk) + n_waves * chunk;
                 base = __builtin_amdgcn_readfirstlane(base);
                 if (base >= count) exhausted = true;
                 else { w_next = base; w_end = min(base + chunk, count); }
@@ -588,7 +594,8 @@ __global__ __launch_bounds__(RGK_TRACE_BLOCK, RGK_BEAM_WAVES) void k_trace_camer
     const SamplerTab tb = {pp.htab, pp.multisample};
     const uint32_t count = (*count_ptr) >> 3; // bundles: 8 slots each
     const uint32_t chunk = fetch_chunk(count, gridDim.x * (RGK_TRACE_BLOCK / 64), 16u);
-    uint32_t w_next = 0, w_end = 0;
+    const uint32_t n_waves = gridDim.x * (RGK_TRACE_BLOCK / 64), wave_id = blockIdx.x * (RGK_TRACE_BLOCK / 64) + (threadIdx.x >> 6);
+    uint32_t w_next = min(wave_id * chunk, count), w_end = min(w_next + chunk, count); // first slice dealt statically (see trace_persistent)
     bool exhausted = false;
     uint32_t n_nodes = 0, n_tris = 0;
     // per-lane bundle state
@@ -631,7 +638,8 @@ __global__ __launch_bounds__(RGK_TRACE_BLOCK, RGK_BEAM_WAVES) void k_trace_camer
         if (nact <= RGK_REFILL_BELOW && !(exhausted && w_next >= w_end)) {
             if (w_next >= w_end) {
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(fetch, chunk);
+                if (n_waves * chunk >= count) base = count;
+                else if (lane == 0) base = atomicAdd(fetch, chunk) + n_waves * chunk;
                 base = __builtin_amdgcn_readfirstlane(base);
                 if (base >= count) exhausted = true;
                 else { w_next = base; w_end = min(base + chunk, count); }
