@@ -63,6 +63,9 @@ struct TriShade {
 // in the float4 texel pool.  RGB8: same, b indexes the RGBA8 pool (one dword per texel) and c the
 // texture's 256-entry byte -> float table in the LUT pool.
 #define RGK_TEXREF_NONE 0xffffffffu
+#ifndef RGK_TEX_TILED
+#define RGK_TEX_TILED 1 // byte texels in tiles of 8 x 4 = one 128-byte line (rgk_device.h tex_row / tex_col, rgk_host.cpp texel pool); 0: row by row
+#endif
 struct TexRef {
     uint32_t kind, a, b, c;
 };

@@ -231,8 +231,19 @@ __device__ __forceinline__ bool decide_and_rescale(float& sample, float probabil
 // ------------------------------------------------------------------ textures (a14)
 __device__ __forceinline__ float glm_repeat(float x) { return x - floorf(x); }
 __device__ __forceinline__ uint32_t tex_kind(const TexRef t) { return t.kind; }
-__device__ __forceinline__ uint32_t tex_row(const TexRef t, int y) { return (uint32_t)y * (t.a & 0xffffu); }
-__device__ __forceinline__ uint32_t tex_col(const TexRef t, int x) { return (uint32_t)x; }
+// Texel index = tex_row(y) + tex_col(x).  Float texels (16 bytes each) lie row by row.  Byte texels (4 bytes each, RGK_TEX_RGB8) lie
+// in tiles of 8 x 4 texels = ONE 128-byte line -- the unit every miss moves (FETCH_SIZE calibration): the 2 x 2
+// footprint of GetPixelInterpolated and the three taps of the bump slopes then sit in one line two times in three instead of
+// always straddling two rows.  Tiles row by row, the image padded up to whole tiles (rgk_host.cpp lays them out the same way).
+__device__ __forceinline__ uint32_t tex_row(const TexRef t, int y) {
+    const uint32_t w = t.a & 0xffffu;
+    if (RGK_TEX_TILED && t.kind == RGK_TEX_RGB8) return ((uint32_t)y >> 2) * (((w + 7u) >> 3) << 5) + (((uint32_t)y & 3u) << 3);
+    return (uint32_t)y * w;
+}
+__device__ __forceinline__ uint32_t tex_col(const TexRef t, int x) {
+    if (RGK_TEX_TILED && t.kind == RGK_TEX_RGB8) return (((uint32_t)x >> 3) << 5) + ((uint32_t)x & 7u);
+    return (uint32_t)x;
+}
 // (Texels in 8 x 4 tiles of one 128-byte line each, so that a bilinear footprint mostly touches one line, were
 // measured: no change in the shade kernel's time, 134.5 vs 135.8 ms.  Row-major, like the reference.)
 // The first byte->float texel tables of the scene are copied into dynamic LDS by every kernel that shades

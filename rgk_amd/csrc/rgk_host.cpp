@@ -1095,15 +1095,23 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
         } else if (t.kind == RGK_TEX_RGB8 || tex_palette[i] >= 0) {
             if (t.width > 65535 || t.height > 65535) return fail(RGK_ERR_UNSUPPORTED, "texture %u larger than 65535 texels on a side", i);
             const size_t n = (size_t)t.width * t.height;
-            if (pool8.size() + n >= (1ull << 30)) return fail(RGK_ERR_UNSUPPORTED, "8-bit texel pool exceeds 2^30 texels"); // 32-bit byte offsets
+            // byte texels lie in tiles of 8 x 4 (one 128-byte line; rgk_device.h tex_row / tex_col), the image padded up to whole tiles
+            const size_t tiles_x = ((size_t)t.width + 7) / 8, tiles_y = ((size_t)t.height + 3) / 4, n_padded = RGK_TEX_TILED ? tiles_x * tiles_y * 32 : n;
+            if (pool8.size() + n_padded >= (1ull << 30)) return fail(RGK_ERR_UNSUPPORTED, "8-bit texel pool exceeds 2^30 texels"); // 32-bit byte offsets
             o.kind = RGK_TEX_RGB8;
             o.a = t.width | (t.height << 16);
+            while (pool8.size() % 32) pool8.push_back(0u); // a tile = a line: the pool itself is 128-byte aligned
             o.b = (uint32_t)pool8.size();
-            pool8.reserve(pool8.size() + n);
+            const size_t pool_at = pool8.size();
+            pool8.resize(pool_at + n_padded, 0u);
+            auto put = [&](size_t k, uint32_t w) { // texel k = y * width + x  ->  its place in the tiled order
+                const size_t x = k % t.width, y = k / t.width;
+                pool8[pool_at + (RGK_TEX_TILED ? ((y >> 2) * tiles_x + (x >> 3)) * 32 + ((y & 3) << 3) + (x & 7) : k)] = w;
+            };
             if (t.kind == RGK_TEX_RGB8) {
                 for (const Palette& p : palettes) if (p.fixed && std::memcmp(&luts[p.lut_off], t.lut, 256 * sizeof(float)) == 0) { o.c = p.lut_off; break; }
                 for (size_t k = 0; k < n; k++)
-                    pool8.push_back((uint32_t)t.texels8[3 * k] | ((uint32_t)t.texels8[3 * k + 1] << 8) | ((uint32_t)t.texels8[3 * k + 2] << 16));
+                    put(k, (uint32_t)t.texels8[3 * k] | ((uint32_t)t.texels8[3 * k + 1] << 8) | ((uint32_t)t.texels8[3 * k + 2] << 16));
             } else { // a float texture with few distinct values: its texels as indices into the table (the first entry holding the value)
                 n_float_tex++; n_palettized++;
                 const Palette& p = palettes[(size_t)tex_palette[i]];
@@ -1117,7 +1125,7 @@ int rgk_scene_create(const rgk_scene_desc* d, int device, rgk_scene** out) {
                     return it->second; // present by construction
                 };
                 for (size_t k = 0; k < n; k++)
-                    pool8.push_back(index_of(t.texels[3 * k]) | (index_of(t.texels[3 * k + 1]) << 8) | (index_of(t.texels[3 * k + 2]) << 16));
+                    put(k, index_of(t.texels[3 * k]) | (index_of(t.texels[3 * k + 1]) << 8) | (index_of(t.texels[3 * k + 2]) << 16));
             }
         } else {
             n_float_tex++;
