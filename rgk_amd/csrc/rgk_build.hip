@@ -1,7 +1,8 @@
 // Accelerator build on the device (replaces the reference's CPU kd build, src/scene.cpp:401-657, as the host
 // builder of rgk_host.cpp does -- results are compared, never the structure).
 //
-//   1. Morton key per reference box (30 bits of the centroid inside the scene box, the reference index below them: unique keys)
+//   1. Morton key per reference box (the centroid inside the scene box at as many bits per axis as the 64-bit key leaves beside
+//      the reference index -- 14 at a million references; the index below them: unique keys)
 //   2. radix sort of the 64-bit keys (hipcub)
 //   3. LBVH hierarchy, one thread per internal node (Karras 2012: direction, range by exponential + binary search over the
 //      longest common prefix, split)
@@ -22,30 +23,42 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "device_types.h"
 #include "rgk_build.h"
 
 namespace {
 
-__device__ __forceinline__ uint32_t expand10(uint32_t v) { // 10 bits -> every third bit
-    v = (v | (v << 16)) & 0x030000FFu;
-    v = (v | (v << 8)) & 0x0300F00Fu;
-    v = (v | (v << 4)) & 0x030C30C3u;
-    v = (v | (v << 2)) & 0x09249249u;
+__device__ __forceinline__ unsigned long long expand21(unsigned long long v) { // 21 bits -> every third bit
+    v &= 0x1fffffull;
+    v = (v | (v << 32)) & 0x001f00000000ffffull;
+    v = (v | (v << 16)) & 0x001f0000ff0000ffull;
+    v = (v | (v << 8)) & 0x100f00f00f00f00full;
+    v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
     return v;
 }
 
-__global__ void k_morton(const RgkBuildPrim* __restrict__ prims, uint32_t n, float3 smin, float3 sinv, unsigned long long* __restrict__ keys) {
+// key = Morton code of the box centre (`mbits` bits per axis) above the reference index (`ibits` bits): unique keys.  mbits is
+// what the 64 bits leave beside the index -- 14 per axis at a million references.  (Round 2 used 10 per axis whatever the size: a
+// dense mesh that occupies a tenth of the scene box -- the statue of configs[3] -- then has ~100 cells per axis for a million
+// triangles, thousands of triangles share a code, and below that level the "hierarchy" is the order of their indices.)
+__global__ void k_morton(const RgkBuildPrim* __restrict__ prims, uint32_t n, float3 smin, float3 sinv, int mbits, int ibits, unsigned long long* __restrict__ keys) {
+    const float cells = (float)(1u << mbits), top = cells - 1.f;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const RgkBuildPrim p = prims[i];
         const float cx = 0.5f * (p.bmin[0] + p.bmax[0]), cy = 0.5f * (p.bmin[1] + p.bmax[1]), cz = 0.5f * (p.bmin[2] + p.bmax[2]);
-        const uint32_t x = (uint32_t)fminf(fmaxf((cx - smin.x) * sinv.x * 1024.f, 0.f), 1023.f);
-        const uint32_t y = (uint32_t)fminf(fmaxf((cy - smin.y) * sinv.y * 1024.f, 0.f), 1023.f);
-        const uint32_t z = (uint32_t)fminf(fmaxf((cz - smin.z) * sinv.z * 1024.f, 0.f), 1023.f);
-        const uint32_t code = (expand10(x) << 2) | (expand10(y) << 1) | expand10(z);
-        keys[i] = ((unsigned long long)code << 32) | i;
+        const uint32_t x = (uint32_t)fminf(fmaxf((cx - smin.x) * sinv.x * cells, 0.f), top);
+        const uint32_t y = (uint32_t)fminf(fmaxf((cy - smin.y) * sinv.y * cells, 0.f), top);
+        const uint32_t z = (uint32_t)fminf(fmaxf((cz - smin.z) * sinv.z * cells, 0.f), top);
+        const unsigned long long code = (expand21(x) << 2) | (expand21(y) << 1) | expand21(z);
+        keys[i] = (code << ibits) | i;
     }
+}
+// after the hierarchy is built only the reference index of a key is needed
+__global__ void k_strip_keys(unsigned long long* __restrict__ keys, uint32_t n, unsigned long long mask) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) keys[i] &= mask;
 }
 
 // length of the common prefix of keys i and j (unique 64-bit keys), -1 outside the array
@@ -120,6 +133,9 @@ __global__ void k_refit(const RgkBuildPrim* __restrict__ prims, const unsigned l
     }
 }
 
+#ifndef RGK_PLOC_RADIUS
+#define RGK_PLOC_RADIUS 6 // places of the current order on either side in which a cluster looks for its partner (2..8: the same; 16 and more: worse)
+#endif
 #define RGK_ROTATED 0x80000000u // count[]: the node's leaves are not one range of the sorted order any more
 __device__ __forceinline__ BBox unite(const BBox& a, const BBox& b) {
     BBox u;
@@ -173,6 +189,91 @@ __global__ void k_refit_rotate(const RgkBuildPrim* __restrict__ prims, const uns
             }
             p = parent[p];
         }
+    }
+}
+
+// ---- PLOC (parallel locally-ordered clustering, Meister & Bittner 2018) instead of the Karras hierarchy: the tree is built
+// bottom-up from the Morton-ordered references by merging, round after round, every pair of clusters that are each other's
+// best partner -- the one within `radius` places of the current order whose union with it has the smallest surface.  That is
+// a surface-area criterion at every merge, which the prefix hierarchy does not have.  cid: a cluster's child code (>= 0 inner
+// node, < 0 ~(position of a reference in the sorted order)); cbox: its box; cnum: references below it.
+__device__ __forceinline__ bool ploc_better(float a, int lo, int hi, float ba, int blo, int bhi) { // one total order for both partners
+    return a < ba || (a == ba && (lo < blo || (lo == blo && hi < bhi)));
+}
+__global__ void k_ploc_init(const RgkBuildPrim* __restrict__ prims, const unsigned long long* __restrict__ keys, uint32_t n, float pad,
+                            int* __restrict__ cid, BBox* __restrict__ cbox, uint32_t* __restrict__ cnum) {
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        cid[k] = ~(int)k; cnum[k] = 1u;
+        cbox[k] = child_box(~(int)k, nullptr, prims, keys, pad);
+    }
+}
+__global__ void k_ploc_nn(const BBox* __restrict__ cbox, int m, int radius, int* __restrict__ nn) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        const BBox b = cbox[i];
+        float best = __builtin_inff();
+        int bj = -1;
+        const int j0 = max(0, i - radius), j1 = min(m - 1, i + radius);
+        for (int j = j0; j <= j1; j++) {
+            if (j == i) continue;
+            const float a = area(unite(b, cbox[j]));
+            if (bj < 0 || ploc_better(a, min(i, j), max(i, j), best, min(i, bj), max(i, bj))) { best = a; bj = j; }
+        }
+        nn[i] = bj;
+    }
+}
+// inner nodes are numbered from n - 2 downwards in the order they are made, so the last one -- the root -- is node 0
+__global__ void k_ploc_merge(const int* __restrict__ cid, const BBox* __restrict__ cbox, const uint32_t* __restrict__ cnum, const int* __restrict__ nn, int m, int n,
+                             uint32_t* __restrict__ n_made, int* __restrict__ left, int* __restrict__ right, int* __restrict__ parent, int* __restrict__ leaf_parent,
+                             BBox* __restrict__ nbox, uint32_t* __restrict__ count, int* __restrict__ cid2, BBox* __restrict__ cbox2, uint32_t* __restrict__ cnum2,
+                             uint32_t* __restrict__ keep) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        const int j = nn[i];
+        const bool mutual = j >= 0 && nn[j] == i;
+        if (mutual && i > j) { keep[i] = 0u; continue; }
+        keep[i] = 1u;
+        if (!mutual) { cid2[i] = cid[i]; cbox2[i] = cbox[i]; cnum2[i] = cnum[i]; continue; }
+        const int id = n - 2 - (int)atomicAdd(n_made, 1u);
+        const int a = cid[i], b = cid[j];
+        const BBox u = unite(cbox[i], cbox[j]);
+        left[id] = a; right[id] = b;
+        if (a >= 0) parent[a] = id; else leaf_parent[~a] = id;
+        if (b >= 0) parent[b] = id; else leaf_parent[~b] = id;
+        nbox[id] = u; count[id] = cnum[i] + cnum[j];
+        if (id == 0) parent[0] = -1;
+        cid2[i] = id; cbox2[i] = u; cnum2[i] = cnum[i] + cnum[j];
+    }
+}
+__global__ void k_ploc_compact(const uint32_t* __restrict__ keep, const uint32_t* __restrict__ pos, int m, const int* __restrict__ cid2, const BBox* __restrict__ cbox2,
+                               const uint32_t* __restrict__ cnum2, int* __restrict__ cid, BBox* __restrict__ cbox, uint32_t* __restrict__ cnum) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x)
+        if (keep[i]) { const uint32_t p = pos[i]; cid[p] = cid2[i]; cbox[p] = cbox2[i]; cnum[p] = cnum2[i]; }
+}
+// A subtree of that tree is not a range of the Morton order, and the collapse makes leaves of ranges: the references are laid
+// out again in the order of the tree's own leaves (left subtree first).  The place of code c = the references to the left of it =
+// the sum of its left siblings' sizes on the way up.
+__device__ __forceinline__ uint32_t ploc_offset(int c, int p, const int* __restrict__ left, const int* __restrict__ right, const int* __restrict__ parent,
+                                                const uint32_t* __restrict__ count) {
+    uint32_t o = 0;
+    while (p >= 0) {
+        if (right[p] == c) { const int l = left[p]; o += l >= 0 ? count[l] : 1u; }
+        c = p; p = parent[p];
+    }
+    return o;
+}
+__global__ void k_ploc_places(int n, const int* __restrict__ left, const int* __restrict__ right, const int* __restrict__ parent, const int* __restrict__ leaf_parent,
+                              const uint32_t* __restrict__ count, const unsigned long long* __restrict__ keys, uint32_t* __restrict__ first,
+                              uint32_t* __restrict__ place, unsigned long long* __restrict__ keys_out, int* __restrict__ leaf_parent_out) {
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const uint32_t at = ploc_offset(~k, leaf_parent[k], left, right, parent, count);
+        place[k] = at; keys_out[at] = keys[k]; leaf_parent_out[at] = leaf_parent[k];
+        if (k < n - 1) first[k] = ploc_offset(k, parent[k], left, right, parent, count);
+    }
+}
+__global__ void k_ploc_rename(int n, int* __restrict__ left, int* __restrict__ right, const uint32_t* __restrict__ place) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n - 1; i += gridDim.x * blockDim.x) {
+        const int l = left[i], r = right[i];
+        if (l < 0) left[i] = ~(int)place[~l];
+        if (r < 0) right[i] = ~(int)place[~r];
     }
 }
 
@@ -426,24 +527,71 @@ int rgk_build_bvh4_device(hipStream_t st, const RgkBuildPrim* h_prims, uint32_t 
     float3 mn = make_float3(smin[0], smin[1], smin[2]);
     float3 inv = make_float3(smax[0] > smin[0] ? 1.f / (smax[0] - smin[0]) : 0.f, smax[1] > smin[1] ? 1.f / (smax[1] - smin[1]) : 0.f,
                              smax[2] > smin[2] ? 1.f / (smax[2] - smin[2]) : 0.f);
-    k_morton<<<grid, 256, 0, st>>>(prims.p, n, mn, inv, keys.p);
+    int ibits = 1;
+    while (ibits < 32 && (1ull << ibits) < (unsigned long long)n) ibits++;
+    int mbits = std::min(21, (64 - ibits) / 3);
+    if (const char* e = std::getenv("RGK_LBVH_MORTON_BITS")) mbits = std::max(1, std::min(mbits, std::atoi(e))); // experiments (10 = round 2's keys)
+    k_morton<<<grid, 256, 0, st>>>(prims.p, n, mn, inv, mbits, ibits, keys.p);
     {
         size_t tmp_bytes = 0;
-        BCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, keys.p, keys_sorted.p, (int)n, 0, 62, st));
+        BCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, keys.p, keys_sorted.p, (int)n, 0, ibits + 3 * mbits, st));
         Tmp<unsigned char> tmp;
         BCHK(tmp.alloc(tmp_bytes));
-        BCHK(hipcub::DeviceRadixSort::SortKeys(tmp.p, tmp_bytes, keys.p, keys_sorted.p, (int)n, 0, 62, st));
+        BCHK(hipcub::DeviceRadixSort::SortKeys(tmp.p, tmp_bytes, keys.p, keys_sorted.p, (int)n, 0, ibits + 3 * mbits, st));
         BCHK(hipStreamSynchronize(st)); // tmp goes out of scope
     }
     BCHK(hipMemsetAsync(arrived.p, 0, (size_t)n * sizeof(int), st));
-    k_hierarchy<<<grid, 256, 0, st>>>(keys_sorted.p, (int)n, left.p, right.p, parent.p, leaf_parent.p, first.p);
-    BCHK(hipMemsetAsync(count.p, 0, (size_t)n * sizeof(uint32_t), st));
+    int ploc_radius = RGK_PLOC_RADIUS;
+    if (const char* e = std::getenv("RGK_LBVH_PLOC")) ploc_radius = std::max(0, std::min(256, std::atoi(e))); // 0: the Karras hierarchy
+    if (ploc_radius && !std::getenv("RGK_LBVH_ROTATE")) rotate = 0; // (rotations on top of the clustered tree: measured, nothing -- tools/gpu_lbvh_morton_sweep.py)
+    unsigned long long* order = keys_sorted.p; // the reference behind every leaf position (low bits of the key)
+    Tmp<unsigned long long> keys_tree;
+    Tmp<int> leaf_parent_tree;
+    if (!ploc_radius) {
+        k_hierarchy<<<grid, 256, 0, st>>>(keys_sorted.p, (int)n, left.p, right.p, parent.p, leaf_parent.p, first.p);
+        k_strip_keys<<<grid, 256, 0, st>>>(keys_sorted.p, n, (1ull << ibits) - 1ull);
+        BCHK(hipMemsetAsync(count.p, 0, (size_t)n * sizeof(uint32_t), st));
+    } else {
+        k_strip_keys<<<grid, 256, 0, st>>>(keys_sorted.p, n, (1ull << ibits) - 1ull);
+        Tmp<int> cid, cid2, nn;
+        Tmp<BBox> cbox, cbox2;
+        Tmp<uint32_t> cnum, cnum2, keep, pos, place;
+        BCHK(cid.alloc(n)); BCHK(cid2.alloc(n)); BCHK(nn.alloc(n)); BCHK(cbox.alloc(n)); BCHK(cbox2.alloc(n));
+        BCHK(cnum.alloc(n)); BCHK(cnum2.alloc(n)); BCHK(keep.alloc(n)); BCHK(pos.alloc(n)); BCHK(place.alloc(n));
+        BCHK(keys_tree.alloc(n)); BCHK(leaf_parent_tree.alloc(n));
+        size_t scan_bytes = 0;
+        BCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, keep.p, pos.p, (int)n, st));
+        Tmp<unsigned char> scan_tmp;
+        BCHK(scan_tmp.alloc(scan_bytes));
+        BCHK(hipMemsetAsync(ctr.p + 2, 0, sizeof(uint32_t), st)); // ctr[2] = inner nodes made so far
+        k_ploc_init<<<grid, 256, 0, st>>>(prims.p, keys_sorted.p, n, pad, cid.p, cbox.p, cnum.p);
+        uint32_t m = n;
+        for (int round = 0; m > 1; round++) {
+            if (round > 4096) { *err = "device BVH: clustering does not converge"; return -5; }
+            const int g = (int)std::min<uint32_t>((m + 255) / 256, 256 * 16);
+            k_ploc_nn<<<g, 256, 0, st>>>(cbox.p, (int)m, ploc_radius, nn.p);
+            k_ploc_merge<<<g, 256, 0, st>>>(cid.p, cbox.p, cnum.p, nn.p, (int)m, (int)n, ctr.p + 2, left.p, right.p, parent.p, leaf_parent.p, nbox.p, count.p,
+                                            cid2.p, cbox2.p, cnum2.p, keep.p);
+            BCHK(hipcub::DeviceScan::ExclusiveSum(scan_tmp.p, scan_bytes, keep.p, pos.p, (int)m, st));
+            k_ploc_compact<<<g, 256, 0, st>>>(keep.p, pos.p, (int)m, cid2.p, cbox2.p, cnum2.p, cid.p, cbox.p, cnum.p);
+            uint32_t made = 0;
+            BCHK(hipMemcpyAsync(&made, ctr.p + 2, sizeof(made), hipMemcpyDeviceToHost, st));
+            BCHK(hipStreamSynchronize(st));
+            if (n - made >= m) { *err = "device BVH: a clustering round merged nothing"; return -5; }
+            m = n - made;
+        }
+        k_ploc_places<<<grid, 256, 0, st>>>((int)n, left.p, right.p, parent.p, leaf_parent.p, count.p, keys_sorted.p, first.p, place.p, keys_tree.p, leaf_parent_tree.p);
+        k_ploc_rename<<<grid, 256, 0, st>>>((int)n, left.p, right.p, place.p);
+        BCHK(hipMemcpyAsync(leaf_parent.p, leaf_parent_tree.p, (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, st));
+        order = keys_tree.p;
+        BCHK(hipStreamSynchronize(st)); // the round's temporaries go out of scope
+    }
     for (int pass = 0; pass < rotate; pass++) { // each pass: the whole tree bottom-up, one rotation per node at most
         if (pass) BCHK(hipMemsetAsync(arrived.p, 0, (size_t)n * sizeof(int), st));
-        k_refit_rotate<<<grid, 256, 0, st>>>(prims.p, keys_sorted.p, (int)n, pad, left.p, right.p, parent.p, leaf_parent.p, arrived.p, nbox.p, count.p);
+        k_refit_rotate<<<grid, 256, 0, st>>>(prims.p, order, (int)n, pad, left.p, right.p, parent.p, leaf_parent.p, arrived.p, nbox.p, count.p);
     }
-    if (!rotate) k_refit<<<grid, 256, 0, st>>>(prims.p, keys_sorted.p, (int)n, pad, left.p, right.p, parent.p, leaf_parent.p, arrived.p, nbox.p, count.p);
-    k_gather_recs<<<grid, 256, 0, st>>>(keys_sorted.p, n, prims.p, d_recs, d_leaf_recs, d_leaf_pb);
+    if (!rotate) k_refit<<<grid, 256, 0, st>>>(prims.p, order, (int)n, pad, left.p, right.p, parent.p, leaf_parent.p, arrived.p, nbox.p, count.p);
+    k_gather_recs<<<grid, 256, 0, st>>>(order, n, prims.p, d_recs, d_leaf_recs, d_leaf_pb);
     // collapse, level by level.  ctr[0] = nodes allocated, ctr[1] = next frontier length
     uint32_t h[2] = {1u, 0u};
     BCHK(hipMemcpyAsync(ctr.p, h, sizeof(h), hipMemcpyHostToDevice, st));
@@ -454,7 +602,7 @@ int rgk_build_bvh4_device(hipStream_t st, const RgkBuildPrim* h_prims, uint32_t 
     while (n_front) {
         levels++;
         if (levels > 200) { *err = "device BVH deeper than 200 levels"; return -5; }
-        k_collapse<<<(int)std::min<uint32_t>((n_front + 63) / 64, 4096), 64, 0, st>>>(cur, n_front, nxt, ctr.p + 1, ctr.p, max_leaf, pad, prims.p, keys_sorted.p,
+        k_collapse<<<(int)std::min<uint32_t>((n_front + 63) / 64, 4096), 64, 0, st>>>(cur, n_front, nxt, ctr.p + 1, ctr.p, max_leaf, pad, prims.p, order,
                                                                                      left.p, right.p, nbox.p, count.p, first.p, d_nodes);
         BCHK(hipMemcpyAsync(h, ctr.p, sizeof(h), hipMemcpyDeviceToHost, st));
         BCHK(hipStreamSynchronize(st));
