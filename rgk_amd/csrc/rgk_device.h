@@ -307,21 +307,9 @@ __device__ __forceinline__ f3 tex_get(const DevScene& sc, const TexRef t, float2
     f3 c1s = fx * c10 + (1.0f - fx) * c11;
     return fy * c0s + (1.0f - fy) * c1s;
 }
-// The first texel tex_get(t, uv) will read, asked for EARLY: a vertex's colour and diffuse maps are read after its bump map has
-// tilted the normal (their LTC lookups need the tilted frame), three dependent round trips to memory where the addresses of all
-// three are known as soon as uv is.  The caller keeps the returned word alive until after the real fetch (an empty asm that reads
-// it), so the load is issued here and nothing waits for it before then.
-#ifndef RGK_TEX_TOUCH
-#define RGK_TEX_TOUCH 0
-#endif
-__device__ __forceinline__ uint32_t tex_touch(const DevScene& sc, const TexRef t, float2 uv) {
-    if (tex_kind(t) != RGK_TEX_RGB8) return 0u;
-    const int xsize = (int)(t.a & 0xffffu), ysize = (int)(t.a >> 16);
-    int ix0 = (int)truncf(glm_repeat(uv.x) * xsize - 0.5f), iy0 = (int)truncf(glm_repeat(uv.y) * ysize - 0.5f);
-    if (ix0 == -1) ix0 = 0;
-    if (iy0 == -1) iy0 = 0;
-    return gld_u32(sc.texels8, (t.b + tex_row(t, iy0) + tex_col(t, ix0)) << 2);
-}
+// (Asking for the first texel of the colour and diffuse maps EARLY -- as soon as uv is known, before the bump map's round trip,
+// the word kept alive until after the real fetch -- was measured again in round 3 on top of the tiled layout: first vertices 31.2 ->
+// 32.2 ms per round, later vertices 24.9 -> 26.5.  The shading kernels do not wait for texels; not kept.)
 // GetSlopeRight / GetSlopeBottom, reference src/texture.cpp:79-102
 __device__ __forceinline__ void tex_slopes(const DevScene& sc, const TexRef t, float2 uv, float& right, float& bottom) {
     right = 0.f; bottom = 0.f;

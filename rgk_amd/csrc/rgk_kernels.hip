@@ -127,8 +127,6 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, RGK_SHADE_WAVES) void k_shade(cons
                         uv.y = ia * g1.w + ib * g3.w + ic * g5.w;
                     }
                     const bool bumped = tex_kind(mat.t_bump) != RGK_TEXREF_NONE;
-                    uint32_t touch_c = 0u, touch_d = 0u;
-                    if (RGK_TEX_TOUCH && !GENERIC) { touch_c = tex_touch(sc, mat.t_color, uv); touch_d = tex_touch(sc, mat.t_diffuse, uv); }
                     f3 lightN = faceN;
                     if (bumped) { // bump, path_tracer.cpp:204-231
                         float right, bottom;
@@ -176,7 +174,6 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, RGK_SHADE_WAVES) void k_shade(cons
                     MatPrep mp;
                     if (!nee_dead) mat_prepare(sc, mat, uv, VrL, !ends, mp);
                     else { mp.fast = true; mp.lobe = false; mp.diffc = mp.colorc = mk3(0.f, 0.f, 0.f); }
-                    if (RGK_TEX_TOUCH && !GENERIC) asm volatile("" :: "v"(touch_c), "v"(touch_d)); // (tex_touch: alive until here)
                     const f3 contribution = cum; // excludes this vertex's own coefficients, :135
                     bool inside = false;
                     f3 dir = mk3(0.f, 0.f, 0.f);
