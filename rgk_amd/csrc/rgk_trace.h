@@ -161,6 +161,11 @@ __device__ __forceinline__ float cvt_ubyte(uint32_t w, int c) { return (float)((
 // Most vertices have the NEE ray only (a light sub-path needs its first ray to hit the scene), so everything that ray needs sits
 // behind the queue index alone: one round of loads per refill, as for a plain shadow ray.  Between rays a lane keeps the sum,
 // the mask and the queue index; the vertex itself is read again for the (rare) later rays and for the total.
+__device__ __forceinline__ int lds_pop(const int* p) {
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((uint32_t)(uintptr_t)p) : "memory");
+    return v;
+}
 template <bool ANY, bool COUNT, int STACK, int LDSN, bool RAYGEN = false, bool JOB = false>
 __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float4* __restrict__ q0, const float4* __restrict__ q1,
                                                  const float4* __restrict__ q2, const float2* __restrict__ nearfar,
@@ -214,7 +219,15 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
             seg_pending = false;                                                                                                       \
         } else jsum = jsum + rad;                                                                                                      \
     }
+// (The LDS part is read by an explicit ds_read_b32.  Written as a plain conditional the compiler folds the two sources into ONE
+// flat_load of a selected pointer -- also with the sides forced to values, also through a volatile pointer: then a system-coherent
+// flat load -- and every pop, nearly all of which come from LDS, takes the flat path: a vector-memory AND an LDS operation, waited
+// for as both.  The low half of a generic pointer into LDS is its LDS address.)
+#if defined(RGK_POP_FLAT)
 #define RGK_POP() ((LDSN >= STACK || sp < LDSN) ? stack[sp * stride] : ovf[(size_t)(sp - LDSN) * ostride])
+#else
+#define RGK_POP() ((LDSN >= STACK || sp < LDSN) ? lds_pop(stack + sp * stride) : ovf[(size_t)(sp - LDSN) * ostride])
+#endif
     for (;;) {
         // ------------------------------------------------ refill idle lanes
         // (JOB: a lane whose ray is done but whose vertex has more waits like an idle lane -- `act` counts the lanes with a ray in
