@@ -50,7 +50,10 @@ RGK_HD double rgk_sqrt(double x) {
  * r = x - n * pi/2 in two steps (pi/2 = hi + lo), Taylor polynomials of degree 11 / 12 on |r| <= pi/4 (truncation
  * < 2e-11), quadrant from n.  Exact for the arguments the path makes (|x| <= 2 pi); defined, if less accurate, up to
  * |x| ~ 1e9 (beyond: NaN in, NaN out; huge finite values lose the reduction's guard bits but stay deterministic). */
-RGK_HD void rgk_sincosf(float x, float* s, float* c) {
+typedef struct rgk_sincos { float s, c; } rgk_sincos;
+/* (by value: through two pointers the device compiler merges the bodies of two call sites into one block that stores through a
+ * SELECTED pointer, which keeps the four results in scratch memory -- 24 bytes and 17 scratch instructions in every shading kernel) */
+RGK_HD rgk_sincos rgk_sincosf_v(float x) {
     const double xd = (double)x;
     const double q = xd * 0.63661977236758134308; /* 2/pi */
     const double big = 6755399441055744.0;        /* 1.5 * 2^52 */
@@ -66,11 +69,14 @@ RGK_HD void rgk_sincosf(float x, float* s, float* c) {
     const int k = (int)(n & 3);
     const double sv = (k == 0) ? ps : (k == 1) ? pc : (k == 2) ? -ps : -pc;
     const double cv = (k == 0) ? pc : (k == 1) ? -ps : (k == 2) ? -pc : ps;
-    *s = (float)sv;
-    *c = (float)cv;
+    rgk_sincos r_;
+    r_.s = (float)sv;
+    r_.c = (float)cv;
+    return r_;
 }
-RGK_HD float rgk_sinf(float x) { float s, c; rgk_sincosf(x, &s, &c); return s; }
-RGK_HD float rgk_cosf(float x) { float s, c; rgk_sincosf(x, &s, &c); return c; }
+RGK_HD void rgk_sincosf(float x, float* s, float* c) { const rgk_sincos r_ = rgk_sincosf_v(x); *s = r_.s; *c = r_.c; }
+RGK_HD float rgk_sinf(float x) { return rgk_sincosf_v(x).s; }
+RGK_HD float rgk_cosf(float x) { return rgk_sincosf_v(x).c; }
 
 /* asin(t) for 0 <= t <= 0.5 in double: t + t^3 * P(t^2), P = the Taylor series of (asin(t) - t) / t^3 to 14 terms
  * (the 15th is < 3e-11 at t = 0.5). */

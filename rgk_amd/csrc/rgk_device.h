@@ -90,8 +90,8 @@ __device__ __forceinline__ quatf qinverse(quatf q) {
     return r;
 }
 __device__ __forceinline__ quatf angle_axis(float a, f3 axis) {
-    float s, c;
-    rgk_sincosf(a * 0.5f, &s, &c);
+    const rgk_sincos sc_ = rgk_sincosf_v(a * 0.5f);
+    const float s = sc_.s, c = sc_.c;
     quatf r; r.w = c; r.x = axis.x * s; r.y = axis.y * s; r.z = axis.z * s;
     return r;
 }
@@ -198,8 +198,8 @@ __device__ __forceinline__ float sample1d_t(const SamplerTab& tb, uint32_t seed,
 __device__ __forceinline__ float2 disc_uniform(float2 s) {
     float r = sqrtf(s.x);
     float a = (float)((double)(s.y * 2.0f) * 3.14159265358979323846);
-    float sn, cs;
-    rgk_sincosf(a, &sn, &cs);
+    const rgk_sincos sc_ = rgk_sincosf_v(a);
+    const float sn = sc_.s, cs = sc_.c;
     return make_float2(r * sn, r * cs);
 }
 __device__ __forceinline__ f3 hemisphere_cosine_z(float2 s) {
@@ -216,8 +216,8 @@ __device__ __forceinline__ f3 sphere_uniform(float2 s) {
     float z = s.x * 2.0f - 1.0f;
     float a = (float)((double)s.y * 6.283185);
     float r = sqrtf(1 - z * z);
-    float sn, cs;
-    rgk_sincosf(a, &sn, &cs);
+    const rgk_sincos sc_ = rgk_sincosf_v(a);
+    const float sn = sc_.s, cs = sc_.c;
     return mk3(r * cs, r * sn, z);
 }
 __device__ __forceinline__ bool decide_and_rescale(float& sample, float probability) {
@@ -573,25 +573,30 @@ struct MatPrep {
 };
 __device__ __forceinline__ bool mat_is_fast(uint32_t k) { return k == RGK_BXDF_DIFFUSE || k >= RGK_BXDF_LTC_BECKMANN; } // MatPrep::fast
 __device__ __forceinline__ void mat_prepare(const DevScene& sc, const DevMaterial& m, float2 uv, f3 VrL, bool need_sample, MatPrep& e) {
-    e.fast = false;
-    e.lobe = false;
-    e.diffc = e.colorc = mk3(0.f, 0.f, 0.f);
+    // (The two colours are formed as VALUES and stored once, at the end.  Stored from where they are fetched -- e.colorc = tex_get(..);
+    // e.diffc = tex_get(..) -- the compiler merges the two fetches' tails into one block that stores through a SELECTED pointer
+    // before this function is inlined, and the kernel then keeps both colours in scratch memory: 24 bytes and 17 scratch
+    // instructions per vertex in every shading kernel.)
+    bool fast = false, lobe = false;
+    f3 diffc = mk3(0.f, 0.f, 0.f), colorc = diffc;
     const uint32_t k = m.kind;
     if (k == RGK_BXDF_DIFFUSE) {
-        e.fast = true;
-        e.diffc = tex_get(sc, m.t_diffuse, uv);
+        fast = true;
+        diffc = tex_get(sc, m.t_diffuse, uv);
     } else if (k >= RGK_BXDF_LTC_BECKMANN) {
-        e.fast = true;
-        e.colorc = tex_get(sc, m.t_color, uv);
-        if (k >= RGK_BXDF_LTC_BECKMANN_DIFFUSE) e.diffc = tex_get(sc, m.t_diffuse, uv);
-        e.lobe = !is_zero3(e.colorc);
-        if (e.lobe) {
+        fast = true;
+        colorc = tex_get(sc, m.t_color, uv);
+        if (k >= RGK_BXDF_LTC_BECKMANN_DIFFUSE) diffc = tex_get(sc, m.t_diffuse, uv);
+        lobe = !is_zero3(colorc);
+        if (lobe) {
             const uint32_t tab = (k == RGK_BXDF_LTC_GGX || k == RGK_BXDF_LTC_GGX_DIFFUSE) ? 0u : RGK_LTC_TABLE_BYTES; // GGX table, then Beckmann, in one buffer
             const float theta = ltc_theta(VrL);
             e.Mv = ltc_bilinear(sc.ltc, tab, theta, m.roughness);
             e.Ms = (theta >= RGK_PI_F / 4.0f || !need_sample) ? e.Mv : ltc_bilinear(sc.ltc, tab, RGK_PI_F / 4.0f, m.roughness);
         }
     }
+    e.fast = fast; e.lobe = lobe;
+    e.diffc = diffc; e.colorc = colorc;
 }
 // GENERIC = false: the caller guarantees a fast-route material (the generic route is compiled out)
 template <bool GENERIC = true>
