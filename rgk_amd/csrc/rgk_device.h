@@ -283,6 +283,34 @@ __device__ __forceinline__ f3 texel_at(const DevScene& sc, const TexRef t, uint3
     const float4 v = gld_f4(sc.texels, (t.b + idx) << 4);
     return mk3(v.x, v.y, v.z);
 }
+// N texels of one texture with their loads IN FLIGHT TOGETHER: one decision about the texel format and one about where the table
+// lives, then N loads, then N decodes.  Texel by texel (texel_at in a row) every fetch sits behind its own format branches, so the
+// compiler waits for each word before it asks for the next: the four taps of GetPixelInterpolated and the three of the bump
+// slopes were seven round trips to memory one after the other, per texture.
+template <int N>
+__device__ __forceinline__ void texels_at(const DevScene& sc, const TexRef t, const uint32_t (&idx)[N], f3 (&out)[N]) {
+    if (tex_kind(t) == RGK_TEX_RGB8) {
+        uint32_t w[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) w[k] = gld_u32(sc.texels8, (t.b + idx[k]) << 2);
+        if (t.c + 256u <= RGK_LDS_LUT_FLOATS) {
+            const float* lut = rgk_lut_lds + t.c;
+#pragma unroll
+            for (int k = 0; k < N; k++) out[k] = mk3(lut[w[k] & 0xffu], lut[(w[k] >> 8) & 0xffu], lut[(w[k] >> 16) & 0xffu]);
+        } else {
+            const uint32_t lut = t.c << 2;
+#pragma unroll
+            for (int k = 0; k < N; k++)
+                out[k] = mk3(gld_f32(sc.luts, lut + ((w[k] & 0xffu) << 2)), gld_f32(sc.luts, lut + ((w[k] >> 6) & 0x3fcu)), gld_f32(sc.luts, lut + ((w[k] >> 14) & 0x3fcu)));
+        }
+    } else {
+        float4 v[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) v[k] = gld_f4(sc.texels, (t.b + idx[k]) << 4);
+#pragma unroll
+        for (int k = 0; k < N; k++) out[k] = mk3(v[k].x, v[k].y, v[k].z);
+    }
+}
 // ReadableTexture::GetPixelInterpolated, reference src/texture.cpp:35-77 (FileTexture) and
 // src/texture.hpp:64-80 (Solid / Empty)
 __device__ __forceinline__ f3 tex_get(const DevScene& sc, const TexRef t, float2 uv) {
@@ -299,8 +327,10 @@ __device__ __forceinline__ f3 tex_get(const DevScene& sc, const TexRef t, float2
     if (ix0 == -1) ix0 = 0;
     if (iy0 == -1) iy0 = 0;
     const uint32_t r0 = tex_row(t, iy0), r1 = tex_row(t, iy1), k0 = tex_col(t, ix0), k1 = tex_col(t, ix1);
-    f3 c00 = texel_at(sc, t, r0 + k0), c01 = texel_at(sc, t, r0 + k1);
-    f3 c10 = texel_at(sc, t, r1 + k0), c11 = texel_at(sc, t, r1 + k1);
+    const uint32_t idx[4] = {r0 + k0, r0 + k1, r1 + k0, r1 + k1};
+    f3 c[4];
+    texels_at<4>(sc, t, idx, c);
+    const f3 c00 = c[0], c01 = c[1], c10 = c[2], c11 = c[3];
     fy = 1.0f - fy;
     fx = 1.0f - fx;
     f3 c0s = fx * c00 + (1.0f - fx) * c01;
@@ -322,9 +352,10 @@ __device__ __forceinline__ void tex_slopes(const DevScene& sc, const TexRef t, f
     if (x == -1) x = 0;
     if (y == -1) y = 0;
     const uint32_t r0 = tex_row(t, y), k0 = tex_col(t, x);
-    f3 here = texel_at(sc, t, r0 + k0);
-    f3 tr = texel_at(sc, t, r0 + tex_col(t, x2));
-    f3 tb = texel_at(sc, t, tex_row(t, y2) + k0);
+    const uint32_t idx[3] = {r0 + k0, r0 + tex_col(t, x2), tex_row(t, y2) + k0};
+    f3 c[3];
+    texels_at<3>(sc, t, idx, c);
+    const f3 here = c[0], tr = c[1], tb = c[2];
     float a = (here.x + here.y + here.z) / 3;
     right = a - (tr.x + tr.y + tr.z) / 3;
     bottom = a - (tb.x + tb.y + tb.z) / 3;
