@@ -312,10 +312,12 @@ __device__ __forceinline__ void texels_at(const DevScene& sc, const TexRef t, co
     }
 }
 // ReadableTexture::GetPixelInterpolated, reference src/texture.cpp:35-77 (FileTexture) and
-// src/texture.hpp:64-80 (Solid / Empty)
-__device__ __forceinline__ f3 tex_get(const DevScene& sc, const TexRef t, float2 uv) {
-    if (tex_kind(t) == RGK_TEXREF_NONE) return mk3(0.f, 0.f, 0.f);
-    if (tex_kind(t) == RGK_TEX_SOLID) return mk3(__uint_as_float(t.a), __uint_as_float(t.b), __uint_as_float(t.c));
+// src/texture.hpp:64-80 (Solid / Empty): the four taps and the two weights ...
+struct TexFoot {
+    uint32_t idx[4]; // r0 + k0, r0 + k1, r1 + k0, r1 + k1
+    float fx, fy;
+};
+__device__ __forceinline__ TexFoot tex_foot(const TexRef t, float2 uv) {
     const int xsize = (int)(t.a & 0xffffu), ysize = (int)(t.a >> 16);
     float x = glm_repeat(uv.x) * xsize - 0.5f;
     float y = glm_repeat(uv.y) * ysize - 0.5f;
@@ -327,16 +329,29 @@ __device__ __forceinline__ f3 tex_get(const DevScene& sc, const TexRef t, float2
     if (ix0 == -1) ix0 = 0;
     if (iy0 == -1) iy0 = 0;
     const uint32_t r0 = tex_row(t, iy0), r1 = tex_row(t, iy1), k0 = tex_col(t, ix0), k1 = tex_col(t, ix1);
-    const uint32_t idx[4] = {r0 + k0, r0 + k1, r1 + k0, r1 + k1};
-    f3 c[4];
-    texels_at<4>(sc, t, idx, c);
-    const f3 c00 = c[0], c01 = c[1], c10 = c[2], c11 = c[3];
-    fy = 1.0f - fy;
-    fx = 1.0f - fx;
-    f3 c0s = fx * c00 + (1.0f - fx) * c01;
-    f3 c1s = fx * c10 + (1.0f - fx) * c11;
+    TexFoot f;
+    f.idx[0] = r0 + k0; f.idx[1] = r0 + k1; f.idx[2] = r1 + k0; f.idx[3] = r1 + k1;
+    f.fx = fx; f.fy = fy;
+    return f;
+}
+// ... and the blend
+__device__ __forceinline__ f3 tex_blend(const TexFoot& f, const f3 (&c)[4]) {
+    const float fy = 1.0f - f.fy;
+    const float fx = 1.0f - f.fx;
+    f3 c0s = fx * c[0] + (1.0f - fx) * c[1];
+    f3 c1s = fx * c[2] + (1.0f - fx) * c[3];
     return fy * c0s + (1.0f - fy) * c1s;
 }
+__device__ __forceinline__ f3 tex_get(const DevScene& sc, const TexRef t, float2 uv) {
+    if (tex_kind(t) == RGK_TEXREF_NONE) return mk3(0.f, 0.f, 0.f);
+    if (tex_kind(t) == RGK_TEX_SOLID) return mk3(__uint_as_float(t.a), __uint_as_float(t.b), __uint_as_float(t.c));
+    const TexFoot f = tex_foot(t, uv);
+    f3 c[4];
+    texels_at<4>(sc, t, f.idx, c);
+    return tex_blend(f, c);
+}
+// (A material's colour and diffuse maps fetched as ONE batch of eight taps: measured, nothing alone and slower together with other
+// hoisted loads -- the kernel is at its 128 registers.)
 // (Asking for the first texel of the colour and diffuse maps EARLY -- as soon as uv is known, before the bump map's round trip,
 // the word kept alive until after the real fetch -- was measured again in round 3 on top of the tiled layout: first vertices 31.2 ->
 // 32.2 ms per round, later vertices 24.9 -> 26.5.  The shading kernels do not wait for texels; not kept.)
