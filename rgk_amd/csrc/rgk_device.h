@@ -244,8 +244,6 @@ __device__ __forceinline__ uint32_t tex_col(const TexRef t, int x) {
     if (RGK_TEX_TILED && t.kind == RGK_TEX_RGB8) return (((uint32_t)x >> 3) << 5) + ((uint32_t)x & 7u);
     return (uint32_t)x;
 }
-// (Texels in 8 x 4 tiles of one 128-byte line each, so that a bilinear footprint mostly touches one line, were
-// measured: no change in the shade kernel's time, 134.5 vs 135.8 ms.  Row-major, like the reference.)
 // The first byte->float texel tables of the scene are copied into dynamic LDS by every kernel that shades
 // (lut_lds_fill at kernel entry; launch with RGK_LDS_LUT_FLOATS * 4 bytes of dynamic LDS): the three dependent
 // table loads per texel were 7 % of the shade kernel.

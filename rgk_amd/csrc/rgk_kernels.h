@@ -12,6 +12,9 @@
 #ifndef RGK_SHADE_BLOCK
 #define RGK_SHADE_BLOCK 512
 #endif
+#ifndef RGK_SHADE_BLOCK_LATER
+#define RGK_SHADE_BLOCK_LATER 256 // k_shade at bounce >= 1 (see there)
+#endif
 #define RGK_MAX_DEPTH 62
 #define RGK_LV_FLOAT4 6 // float4 per stored light vertex: {pos,mat}{lightN,u}{Vr,v}{light_from_source,valid}{diffuse colour}{specular colour}
 
