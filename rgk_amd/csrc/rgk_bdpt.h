@@ -32,7 +32,7 @@ __device__ __forceinline__ uint32_t block_append(bool flag, uint32_t* counter, u
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t t = 0;
-        for (int k = 0; k < RGK_SHADE_BLOCK / 64; k++) { uint32_t a = s_cnt[k]; s_cnt[k] = t; t += a; }
+        for (int k = 0; k < RGK_LIGHT_BLOCK / 64; k++) { uint32_t a = s_cnt[k]; s_cnt[k] = t; t += a; }
         *s_base = t ? atomicAdd(counter, t) : 0u;
     }
     __syncthreads();
@@ -50,13 +50,20 @@ __device__ __forceinline__ float4* lv_ptr(const PassParams& pp, uint32_t k, uint
 // that is most of them (configs[3]: nine in ten): only the others are queued (same clip, same decision as the traversal
 // kernel's own, rgk_trace.h clip_to_scene) -- the first traversal launch, the hit list and the ray records shrink accordingly.
 // The reference counts every light ray it traces (raycount++, :126); the host adds the culled ones back (RGK_CNT_CULLED).
-__global__ __launch_bounds__(RGK_SHADE_BLOCK) void k_raygen_light(const DevScene sc, const DevCamera cam, const PassParams pp, float4* __restrict__ rayA,
+__global__ __launch_bounds__(RGK_LIGHT_BLOCK) void k_raygen_light(const DevScene sc, const DevCamera cam, const PassParams pp, float4* __restrict__ rayA,
                                                                    float4* __restrict__ rayB, float4* __restrict__ thr, uint32_t* __restrict__ counters) {
     const uint32_t n = pp.npix * pp.ns;
     const SamplerTab tb = {pp.htab, pp.multisample};
-    __shared__ uint32_t s_cnt[RGK_SHADE_BLOCK / 64];
+    // The queued rays are STAGED in LDS and written out a full workgroup's worth at a time: one reservation per 512 QUEUED rays.
+    // Reserving per 512 slots -- nine in ten of which queue nothing on configs[3] -- meant 2 M returning atomics on one word per
+    // round, and at ~88 per microsecond chip-wide those atomics WERE the kernel's 24 ms.  (The per-slot records -- light, start
+    // colour, throughput, the vertex mask -- are indexed by slot, not by queue position, and are written where they are made.)
+    __shared__ uint32_t s_cnt[RGK_LIGHT_BLOCK / 64];
     __shared__ uint32_t s_base;
-    for (uint32_t base = blockIdx.x * RGK_SHADE_BLOCK; base < n; base += gridDim.x * RGK_SHADE_BLOCK) {
+    __shared__ float4 st_a[2 * RGK_LIGHT_BLOCK], st_b[2 * RGK_LIGHT_BLOCK];
+    uint32_t fill = 0; // workgroup-uniform: rays staged so far (< RGK_LIGHT_BLOCK at the top of an iteration)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (uint32_t base = blockIdx.x * RGK_LIGHT_BLOCK; base < n; base += gridDim.x * RGK_LIGHT_BLOCK) {
         const uint32_t slot = base + threadIdx.x;
         bool queue = false;
         float4 a = make_float4(0, 0, 0, 0), b = a, li = a, ls = a;
@@ -90,12 +97,34 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK) void k_raygen_light(const DevScene
             float t0, t1;
             queue = !nan_ray && clip_to_scene(sc, o, d, 0.0f, 10000.0f, t0, t1); // Ray::near / Ray::far defaults, src/ray.hpp:25-26
         }
-        const uint32_t p = block_append(queue, &counters[RGK_CNT_QUEUE], s_cnt, &s_base);
+        const unsigned long long m = __ballot(queue);
+        if (lane == 0) s_cnt[w] = __popcll(m);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < RGK_LIGHT_BLOCK / 64; k++) { const uint32_t c = s_cnt[k]; before += k < w ? c : 0u; total += c; }
         if (queue) {
-            rayA[p] = a; rayB[p] = b;
+            const uint32_t at = fill + before + __popcll(m & ((1ull << lane) - 1ull));
+            st_a[at] = a; st_b[at] = b;
             pp.light[slot] = li; pp.lstart[slot] = ls;
             thr[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(1u << 16));
         }
+        fill += total;
+        __syncthreads(); // the staged rays are visible, s_cnt may be written again
+        if (fill >= RGK_LIGHT_BLOCK) {
+            if (threadIdx.x == 0) s_base = atomicAdd(&counters[RGK_CNT_QUEUE], fill);
+            __syncthreads();
+            const uint32_t q0 = s_base;
+            for (uint32_t k = threadIdx.x; k < fill; k += RGK_LIGHT_BLOCK) { rayA[q0 + k] = st_a[k]; rayB[q0 + k] = st_b[k]; }
+            fill = 0;
+            __syncthreads();
+        }
+    }
+    if (fill) {
+        if (threadIdx.x == 0) s_base = atomicAdd(&counters[RGK_CNT_QUEUE], fill);
+        __syncthreads();
+        const uint32_t q0 = s_base;
+        for (uint32_t k = threadIdx.x; k < fill; k += RGK_LIGHT_BLOCK) { rayA[q0 + k] = st_a[k]; rayB[q0 + k] = st_b[k]; }
     }
 }
 
@@ -138,12 +167,12 @@ __device__ __forceinline__ void path_step(const DevScene& sc, const SamplerTab& 
 
 // Queue indices of the rays that hit something, in queue order inside a workgroup's chunk (the order only decides which lanes
 // shade which vertex): ballot + prefix popcount per wave, waves added through LDS, one atomic per workgroup.
-__global__ __launch_bounds__(RGK_SHADE_BLOCK) void k_list_hits(const float4* __restrict__ hit, const uint32_t* __restrict__ count_ptr,
+__global__ __launch_bounds__(RGK_LIGHT_BLOCK) void k_list_hits(const float4* __restrict__ hit, const uint32_t* __restrict__ count_ptr,
                                                                 uint32_t* __restrict__ list, uint32_t* __restrict__ list_count) {
     const uint32_t count = *count_ptr;
-    __shared__ uint32_t s_cnt[RGK_SHADE_BLOCK / 64];
+    __shared__ uint32_t s_cnt[RGK_LIGHT_BLOCK / 64];
     __shared__ uint32_t s_base;
-    for (uint32_t base = blockIdx.x * RGK_SHADE_BLOCK; base < count; base += gridDim.x * RGK_SHADE_BLOCK) {
+    for (uint32_t base = blockIdx.x * RGK_LIGHT_BLOCK; base < count; base += gridDim.x * RGK_LIGHT_BLOCK) {
         const uint32_t i = base + threadIdx.x;
         const bool h = i < count && __float_as_int(hit[i].w) >= 0;
         const uint32_t p = block_append(h, list_count, s_cnt, &s_base);
@@ -155,7 +184,7 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK) void k_list_hits(const float4* __r
 // route and lists the others (queue indices in pp.generic), the second walks that list with the full BxDF code.
 // ---- light sub-path vertex k: store it, splat it to the camera, continue (russian = -1: no roulette)
 template <bool GENERIC>
-__global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade_light(const DevScene sc, const DevCamera cam, const PassParams pp, const uint32_t k,
+__global__ __launch_bounds__(RGK_LIGHT_BLOCK, 4) void k_shade_light(const DevScene sc, const DevCamera cam, const PassParams pp, const uint32_t k,
                                                                      const float4* __restrict__ rayA, const float4* __restrict__ rayB,
                                                                      const float4* __restrict__ hit, float4* __restrict__ thr,
                                                                      float4* __restrict__ nextA, float4* __restrict__ nextB, float4* __restrict__ shA,
@@ -163,10 +192,10 @@ __global__ __launch_bounds__(RGK_SHADE_BLOCK, 4) void k_shade_light(const DevSce
     const uint32_t count = counters[(GENERIC ? RGK_CNT_GENERIC : RGK_CNT_HITS) + k]; // (the fast launch walks k_list_hits's list)
     const float eps = sc.epsilon;
     const SamplerTab tb = {pp.htab, pp.multisample};
-    __shared__ uint32_t s_cnt[RGK_SHADE_BLOCK / 64];
+    __shared__ uint32_t s_cnt[RGK_LIGHT_BLOCK / 64];
     __shared__ uint32_t s_base;
     lut_lds_fill(sc);
-    for (uint32_t base = blockIdx.x * RGK_SHADE_BLOCK; base < count; base += gridDim.x * RGK_SHADE_BLOCK) {
+    for (uint32_t base = blockIdx.x * RGK_LIGHT_BLOCK; base < count; base += gridDim.x * RGK_LIGHT_BLOCK) {
         const bool valid = base + threadIdx.x < count;
         const uint32_t i = !valid ? 0u : (GENERIC ? pp.generic[base + threadIdx.x] : pp.hitlist[base + threadIdx.x]);
         bool cont = false, splat = false, defer = false;

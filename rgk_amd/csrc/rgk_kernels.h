@@ -12,6 +12,9 @@
 #ifndef RGK_SHADE_BLOCK
 #define RGK_SHADE_BLOCK 512
 #endif
+#ifndef RGK_LIGHT_BLOCK
+#define RGK_LIGHT_BLOCK RGK_SHADE_BLOCK // the light sub-path's kernels (rgk_bdpt.h)
+#endif
 #ifndef RGK_SHADE_BLOCK_LATER
 #define RGK_SHADE_BLOCK_LATER 256 // k_shade at bounce >= 1 (see there)
 #endif

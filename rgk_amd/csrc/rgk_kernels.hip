@@ -894,19 +894,19 @@ static inline int slot_grid(const PassParams& pp) {
 void rgk_launch_raygen_light(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, float4* rayA, float4* rayB,
                              float4* thr, uint32_t* counters) {
     const uint32_t n = pp.npix * pp.ns;
-    k_raygen_light<<<bounded_grid(256 * 4 * 512 / RGK_SHADE_BLOCK, n, RGK_SHADE_BLOCK), RGK_SHADE_BLOCK, 0, st>>>(sc, cam, pp, rayA, rayB, thr, counters);
+    k_raygen_light<<<bounded_grid(256 * 4 * 512 / RGK_LIGHT_BLOCK, n, RGK_LIGHT_BLOCK), RGK_LIGHT_BLOCK, 0, st>>>(sc, cam, pp, rayA, rayB, thr, counters);
 }
 void rgk_launch_shade_light(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t k, const float4* rayA,
                             const float4* rayB, const float4* hit, float4* thr, float4* nextA, float4* nextB, float4* shA, float4* shB,
                             float4* shC, uint32_t* counters) {
-    k_shade_light<false><<<bounded_grid(256 * 4 * 512 / RGK_SHADE_BLOCK, g_bound, RGK_SHADE_BLOCK), RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, k, rayA, rayB, hit, thr, nextA, nextB, shA, shB, shC, counters);
-    k_shade_light<true><<<bounded_grid(256 * 2 * 512 / RGK_SHADE_BLOCK, g_bound, RGK_SHADE_BLOCK), RGK_SHADE_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, k, rayA, rayB, hit, thr, nextA, nextB, shA, shB, shC, counters);
+    k_shade_light<false><<<bounded_grid(256 * 4 * 512 / RGK_LIGHT_BLOCK, g_bound, RGK_LIGHT_BLOCK), RGK_LIGHT_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, k, rayA, rayB, hit, thr, nextA, nextB, shA, shB, shC, counters);
+    k_shade_light<true><<<bounded_grid(256 * 2 * 512 / RGK_LIGHT_BLOCK, g_bound, RGK_LIGHT_BLOCK), RGK_LIGHT_BLOCK, RGK_LDS_SHADE_BYTES, st>>>(sc, cam, pp, k, rayA, rayB, hit, thr, nextA, nextB, shA, shB, shC, counters);
 }
 void rgk_launch_connect(hipStream_t st, const DevScene& sc, const PassParams& pp, uint32_t bounce, float4* jobs, float4* rads, uint32_t* counters) {
     k_connect<<<bounded_grid(256 * 8, g_bound, 256), 256, RGK_LDS_SHADE_BYTES, st>>>(sc, pp, bounce, jobs, rads, counters);
 }
 void rgk_launch_list_hits(hipStream_t st, const float4* hit, const uint32_t* count_ptr, uint32_t* list, uint32_t* list_count) {
-    k_list_hits<<<bounded_grid(256 * 4 * 512 / RGK_SHADE_BLOCK, g_bound, RGK_SHADE_BLOCK), RGK_SHADE_BLOCK, 0, st>>>(hit, count_ptr, list, list_count);
+    k_list_hits<<<bounded_grid(256 * 4 * 512 / RGK_LIGHT_BLOCK, g_bound, RGK_LIGHT_BLOCK), RGK_LIGHT_BLOCK, 0, st>>>(hit, count_ptr, list, list_count);
 }
 void rgk_launch_trace_shadow_jobs(hipStream_t st, const DevScene& sc, const PassParams& pp, const RgkTraceCfg& tc, bool count_stats, const float4* jobs, const float4* rads,
                                   float4* tot, const uint32_t* count_ptr, uint32_t* fetch, unsigned long long* stats) {
