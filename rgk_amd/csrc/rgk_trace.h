@@ -37,6 +37,14 @@
 #ifndef RGK_JOB_REFILL_BELOW
 #define RGK_JOB_REFILL_BELOW 24 // the vertex queue's walker: lanes between two rays of their vertex wait for the refill too
 #endif
+// (per launch kind, swept again at the end of round 3 on Sponza: camera 8 / 16 / 24: 15.9 / 15.6 / 15.6 ms; any-hit 12 / 16 / 24 / 32: 8.9 / 8.7 /
+// 8.4 / 8.4; closest-hit 24 ... 48: flat.  Cornell's short rays would take 48 for the closest-hit launches, 36.4 -> 34.5 ms, and 24 for the shadow ones.)
+#ifndef RGK_REFILL_BELOW_CAMERA
+#define RGK_REFILL_BELOW_CAMERA 24
+#endif
+#ifndef RGK_REFILL_BELOW_ANY
+#define RGK_REFILL_BELOW_ANY 24
+#endif
 #ifndef RGK_REFILL_BELOW
 #define RGK_REFILL_BELOW 24 // refill a wave when at most this many lanes still hold a ray (swept 8..60 with the majority walk: 24 best)
 #endif
@@ -237,7 +245,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, const float
         unsigned long long act = JOB ? __ballot(active && !seg_pending) : occ;
         const int nact = __popcll(act);
         if (COUNT) u_outer_it++;
-        const bool refill_now = nact <= (JOB ? RGK_JOB_REFILL_BELOW : RGK_REFILL_BELOW);
+        const bool refill_now = nact <= (JOB ? RGK_JOB_REFILL_BELOW : RAYGEN ? RGK_REFILL_BELOW_CAMERA : ANY ? RGK_REFILL_BELOW_ANY : RGK_REFILL_BELOW);
         if (refill_now && !(exhausted && w_next >= w_end)) {
             if (COUNT) u_refill++;
             if (w_next >= w_end) {
