@@ -20,6 +20,9 @@
 #include "rgk_device.h"
 #include "rgk_kernels.h"
 
+#ifndef RGK_TRANGE_ATOMIC
+#define RGK_TRANGE_ATOMIC 0
+#endif
 #include "rgk_trace.h" // K2 / K5: persistent traversal with lane refill
 
 #ifndef RGK_SKIP_DEAD_NEE
@@ -704,6 +707,30 @@ __global__ __launch_bounds__(256) void k_group_trange(const PassParams pp, const
         } else if (valid && tmax > 0.f) { atomicMin(&trange[2 * g], __float_as_uint(tmin)); atomicMax(&trange[2 * g + 1], __float_as_uint(tmax)); }
     }
 }
+// The same ranges with ONE WAVE PER GROUP and no atomics: lane = (pixel of the group, sample of a block of 8), the wave walks the
+// pass's sample blocks (with 8 samples side by side in the slot order, 64 consecutive slots = 1 KB per step) and writes the
+// group's two words once.  The atomic form above sends 2 atomics per 64 slots at words that sit 16 groups to a 128-byte line,
+// and consecutive waves ARE consecutive groups: 1.6 ms per 530 M slots at 256 spp, but 21 ms per 212 M at 512 spp (configs[3]:
+// four such passes in a frame's first round).  Distances compare as their bit patterns, as the atomics did.
+__global__ __launch_bounds__(64) void k_group_trange_wave(const PassParams pp, const float4* __restrict__ hit, const uint32_t g_first, const uint32_t groups,
+                                                           uint32_t* __restrict__ trange) {
+    const uint32_t gi = blockIdx.x;
+    if (gi >= groups) return;
+    const uint32_t g = g_first + gi, lane = threadIdx.x, p = lane >> 3, k = lane & 7u;
+    const long long jj = (long long)((unsigned long long)g << RGK_ENTRY_SHIFT) + (long long)p - (long long)pp.j0; // the lane's pixel within the pass
+    const bool pix_ok = jj >= 0 && jj < (long long)pp.npix;
+    uint32_t tmin = 0x7f800000u, tmax = 0u;
+#pragma unroll 4
+    for (uint32_t s0 = 0; s0 < pp.ns; s0 += 8u) {
+        const uint32_t srel = s0 + k;
+        if (pix_ok && srel < pp.ns) {
+            const float4 h = hit[slot_of(pp, (uint32_t)jj, srel)];
+            if (__float_as_int(h.w) >= 0 && h.x > 0.f) { const uint32_t t = __float_as_uint(h.x); tmin = min(tmin, t); tmax = max(tmax, t); }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { tmin = min(tmin, (uint32_t)__shfl_xor((int)tmin, o)); tmax = max(tmax, (uint32_t)__shfl_xor((int)tmax, o)); }
+    if (lane == 0) { trange[2 * (size_t)g] = tmin; trange[2 * (size_t)g + 1] = tmax; }
+}
 __global__ void k_init_trange(uint32_t* trange, uint32_t groups) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < groups; i += gridDim.x * blockDim.x) { trange[2 * i] = 0x7f800000u; trange[2 * i + 1] = 0u; }
 }
@@ -791,11 +818,15 @@ void rgk_launch_entry_points(hipStream_t st, const DevScene& sc, const DevCamera
 // nearest / farthest first hit per pixel group of a finished bounce-0 trace of this pass
 void rgk_launch_group_trange(hipStream_t st, const PassParams& pp, const float4* hit, uint32_t* trange) {
     const uint32_t g_first = pp.j0 >> RGK_ENTRY_SHIFT, g_last = (pp.j0 + pp.npix + RGK_ENTRY_PIX - 1u) >> RGK_ENTRY_SHIFT, groups = g_last - g_first;
+#if RGK_TRANGE_ATOMIC
     k_init_trange<<<(groups + 255u) / 256u, 256, 0, st>>>(trange + 2 * (size_t)g_first, groups);
     const uint32_t n = pp.npix * pp.ns; // every slot of this pass (done once per frame and pixel range, so 16 bytes per path do not matter)
     uint32_t blocks = (n + 255u) / 256u;
     if (blocks > 256u * 64u) blocks = 256u * 64u;
     k_group_trange<<<blocks, 256, 0, st>>>(pp, hit, n, trange);
+#else
+    k_group_trange_wave<<<groups, 64, 0, st>>>(pp, hit, g_first, groups, trange);
+#endif
 }
 void rgk_launch_light_entry_points(hipStream_t st, const DevScene& sc, const DevCamera& cam, const PassParams& pp, uint32_t n_pixels_round, const uint32_t* trange, int* entries, float4* lbox) {
     const uint32_t g_first = pp.j0 >> RGK_ENTRY_SHIFT, g_last = (pp.j0 + pp.npix + RGK_ENTRY_PIX - 1u) >> RGK_ENTRY_SHIFT, groups = g_last - g_first;
