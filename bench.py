@@ -81,8 +81,11 @@ def self_launch(n, argv):
 
     def relay(p, dst):
         for line in p.stdout:
-            dst.write(line)
-            dst.flush()
+            # stdout carries the ONE JSON line and nothing else: whatever a library prints on a rank's stdout (gloo's connection
+            # notes, for one) goes to stderr
+            out = dst if (dst is sys.stdout and line.lstrip().startswith("{")) else sys.stderr
+            out.write(line)
+            out.flush()
     threads = [threading.Thread(target=relay, args=(p, sys.stdout if r == 0 else sys.stderr), daemon=True) for r, p in enumerate(procs)]
     for t in threads:
         t.start()
